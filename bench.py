@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- CSPN propagation throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (all n_iter propagation iterations, one C-ABI call)
+over this rank's batch of synthetic affinity + depth tensors, already resident in HBM.
+Workload (config.workload): BASELINE.json configs[2] -- 2D CSPN 3x3, 24 iterations, KITTI
+304x1216 -- at 64 images PER GPU (the full config-3 batch fits one MI355X: 1.0 GB of 288 GB);
+the batch shards embarrassingly, so N>1 is weak scaling with no data-path collective.  The only
+collective is the one-time RCCL broadcast of a backbone-sized weight buffer (outside the timed
+region, reported as broadcast_ms).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BACKBONE_PARAMS = 256_078_272  # resnet50-CSPN fp32 parameter count (probed)
+
+WORKLOADS = {
+    # name: (H, W, n_iter, sparse, depth scale, description)
+    "kitti": (304, 1216, 24, False, 80.0, "BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216"),
+    "kitti_sparse": (304, 1216, 24, True, 80.0, "BASELINE config 4: 2D CSPN 3x3 + sparse-depth replacement (500-pt mask), 24 iters, 304x1216"),
+    "nyu": (228, 304, 24, True, 10.0, "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused"])
+    ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-broadcast", action="store_true")
+    return ap.parse_args()
+
+
+def synth(B, H, W, scale, sparse, device, seed):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    g = torch.randn(B, 8, H, W, generator=gen, device=device)
+    h = torch.rand(B, 1, H, W, generator=gen, device=device) * scale
+    s = None
+    if sparse:
+        m = (torch.rand(B, 1, H, W, generator=gen, device=device) < 500.0 / (H * W)).float()
+        s = m * (torch.rand(B, 1, H, W, generator=gen, device=device) * scale + 0.1)
+    return g, h, s
+
+
+def cpu_baseline(H, W, n_iter, sparse, scale, norm):
+    """The CPU port of the reference path (oracle/cspn_oracle.c, OpenMP over images) on a bounded
+    sample of the same workload, timed on this host's cores."""
+    from oracle import cspn2d_oracle, oracle_threads, set_oracle_threads
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    set_oracle_threads(threads)
+    threads = oracle_threads()
+    nimg = threads  # one image per thread per repetition
+    g, h, s = synth(nimg, H, W, scale, sparse, "cpu", 4242)
+    cspn2d_oracle(g[:1], h[:1], None if s is None else s[:1], 1, norm)  # build/load + warm
+    reps, t_total = 0, 0.0
+    while reps < 3 or (t_total < 4.0 and reps < 20):
+        t0 = time.perf_counter()
+        cspn2d_oracle(g, h, s, n_iter, norm)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    mpix_iters = nimg * H * W * n_iter * reps / 1e6
+    return {
+        "value": round(mpix_iters / t_total, 2),
+        "unit": "Mpix*iters/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d images %dx%d x %d iters x %d reps, oracle/cspn_oracle.c (C port of reference cspn.py, OpenMP over images), host has %d cores"
+                  % (nimg, H, W, n_iter, reps, cores),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import cspn_amd
+    from cspn_amd import _lib
+    lib = cspn_amd.load()
+
+    dist = None
+    broadcast_ms = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if not a.no_broadcast:
+            from cspn_amd.dist import broadcast_flat_
+            buf = torch.empty(BACKBONE_PARAMS, dtype=torch.float32, device=dev).normal_()
+            broadcast_flat_([buf[:1024]])  # communicator warm-up
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            dist.broadcast(buf, src=0)
+            torch.cuda.synchronize()
+            broadcast_ms = (time.perf_counter() - t0) * 1e3
+            del buf
+
+    H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
+    B = a.batch_per_gpu
+    g, h, s = synth(B, H, W, scale, sparse, dev, 1000 + rank)
+    algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
+    algo_name = {1: "stepwise", 2: "fused"}[algo_id]
+    norm = _lib.NORM_TYPES[a.norm_type]
+    ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(h)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                         out.data_ptr(), B, H, W, n_iter, norm, algo_id, ws.data_ptr(), ws_bytes,
+                                         stream.cuda_stream)
+        _lib.check(rc, "cspn2d_forward_f32_algo")
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # per-launch device time: HIP events on the stream the kernels are launched on
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+
+    if dist is not None:
+        t = torch.tensor([elapsed, dev_ms_avg], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms_avg = float(t[0]), float(t[1])
+
+    if rank == 0:
+        px = B * H * W
+        total_mpix_iters = world * px * n_iter * a.steps / 1e6
+        value = total_mpix_iters / elapsed
+        bytes_per_px = 44 if sparse else 40  # guidance 32 + blur 4 (+ sparse 4) + out 4
+        alg_bytes = px * bytes_per_px  # per launch (one forward = all n_iter iterations), per GPU
+        achieved = alg_bytes / (dev_ms_avg * 1e-3) / 1e9
+        res = {
+            "metric": "CSPN iterations/sec (Mpix*iters/s), 3x3x24 at KITTI res" if a.workload.startswith("kitti")
+                      else "CSPN iterations/sec (Mpix*iters/s)",
+            "value": round(value, 1),
+            "unit": "Mpix*iters/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (randn affinity, uniform depth, seeded per rank; generated on device)",
+            "config": {
+                "workload": "%s, batch %d per GPU" % (desc, B),
+                "B_per_gpu": B, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
+                "algo": algo_name, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "cspn2d_fused_kernel (one launch per forward)" if algo_name == "fused"
+                          else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "device_ms_per_launch": round(dev_ms_avg, 4),
+                "device_ms_min": round(dev_ms[0], 4),
+            },
+        }
+        if broadcast_ms is not None:
+            res["broadcast_ms"] = round(broadcast_ms, 3)
+            res["broadcast_bytes"] = BACKBONE_PARAMS * 4
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc))
+                key = "%s_B%d_%s" % (a.workload, B, algo_name)
+                if key in t:
+                    res["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = t[key].get("source")
+            except Exception:
+                pass
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(H, W, n_iter, sparse, scale, a.norm_type)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

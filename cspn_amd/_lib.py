@@ -1,0 +1,69 @@
+"""ctypes binding of libcspn_amd.so (the C ABI in include/cspn_amd.h).
+
+There is NO CPU fallback and no PyTorch re-implementation behind this module:
+if the HIP library is missing or a call fails, it raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcspn_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
+ALGOS = {"auto": 0, "stepwise": 1, "fused": 2}
+ABI_VERSION = 1
+
+_lib = None
+
+
+class CspnError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into cspn_amd/libcspn_amd.so (in-tree)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    if not verbose:
+        args.append("-s")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CspnError(
+            "cspn_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cspn_amd/csrc`). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c_int, c_size_t, vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+    lib.cspn_abi_version.restype = c_int
+    lib.cspn_last_error.restype = ctypes.c_char_p
+    lib.cspn2d_workspace_bytes.restype = c_size_t
+    lib.cspn2d_workspace_bytes.argtypes = [c_int] * 4
+    lib.cspn2d_auto_algo.restype = c_int
+    lib.cspn2d_auto_algo.argtypes = [c_int] * 4
+    lib.cspn2d_forward_f32.restype = c_int
+    lib.cspn2d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp, c_size_t, vp]
+    lib.cspn2d_forward_f32_algo.restype = c_int
+    lib.cspn2d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    lib.cspn3d_workspace_bytes.restype = c_size_t
+    lib.cspn3d_workspace_bytes.argtypes = [c_int] * 5
+    lib.cspn3d_forward_f32.restype = c_int
+    lib.cspn3d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    v = lib.cspn_abi_version()
+    if v != ABI_VERSION:
+        raise CspnError("cspn_amd: ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cspn_last_error().decode("utf-8", "replace")
+        raise CspnError("%s failed (code %d): %s" % (what, rc, msg))

@@ -1,0 +1,116 @@
+// cspn_abi.cpp -- extern "C" entry points declared in include/cspn_amd.h.
+// Replaces the call boundary of Affinity_Propagate.forward
+// (reference cspn_pytorch/models/cspn.py:42-83) and of the chained
+// fluid.layers.affinity_propagate calls (reference cspn_paddle/demo.py:41-52).
+#include <cstdarg>
+#include <cstdio>
+
+#include "cspn_common.h"
+
+namespace cspn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+static int check_common(const void* a, const void* b, const void* out, int n_iter, int norm, const void* ws,
+                        size_t ws_bytes, size_t need) {
+    if (!a || !b || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
+    if (n_iter < 0) { set_error("n_iter must be >= 0 (got %d)", n_iter); return CSPN_E_BADARG; }
+    if (norm < CSPN_NORM_8SUM || norm > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm); return CSPN_E_BADARG; }
+    if (need && (!ws || ws_bytes < need)) {
+        set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+        return CSPN_E_WORKSPACE;
+    }
+    if (need && ((uintptr_t)ws & 255u)) { set_error("workspace must be 256-byte aligned"); return CSPN_E_WORKSPACE; }
+    return 0;
+}
+
+}  // namespace cspn
+
+using namespace cspn;
+
+extern "C" {
+
+int cspn_abi_version(void) { return CSPN_ABI_VERSION; }
+const char* cspn_last_error(void) { return g_err; }
+
+int cspn2d_auto_algo(int B, int H, int W, int n_iter) {
+    return fused2d_supported(B, H, W, n_iter) ? CSPN_ALGO_FUSED : CSPN_ALGO_STEPWISE;
+}
+
+size_t cspn2d_workspace_bytes(int B, int H, int W, int n_iter) {
+    if (B <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    size_t a = stepwise2d_workspace(B, H, W, n_iter);
+    size_t b = fused2d_supported(B, H, W, n_iter) ? fused2d_workspace(B, H, W, n_iter) : 0;
+    return a > b ? a : b;  // large enough for either algo so callers can A/B
+}
+
+int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const float* sparse, float* out, int B,
+                            int H, int W, int n_iter, int norm_type, int algo, void* ws, size_t ws_bytes,
+                            cspn_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d H=%d W=%d", B, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    if (algo == CSPN_ALGO_AUTO) algo = cspn2d_auto_algo(B, H, W, n_iter);
+    if (algo != CSPN_ALGO_STEPWISE && algo != CSPN_ALGO_FUSED) { set_error("unknown algo %d", algo); return CSPN_E_BADARG; }
+    if (algo == CSPN_ALGO_FUSED && !fused2d_supported(B, H, W, n_iter)) {
+        set_error("fused kernel does not support B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter);
+        return CSPN_E_UNSUPPORTED;
+    }
+    size_t need = n_iter == 0 ? 0
+                  : (algo == CSPN_ALGO_FUSED ? fused2d_workspace(B, H, W, n_iter)
+                                             : stepwise2d_workspace(B, H, W, n_iter));
+    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, need)) return e;
+    if (n_iter == 0) {  // reference cspn.py:61,66,83: the loop body never runs
+        hipError_t e = hipMemcpyAsync(out, blur, sizeof(float) * (size_t)B * H * W, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+    }
+    if (algo == CSPN_ALGO_FUSED) return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
+    return stepwise2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
+}
+
+int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sparse, float* out, int B, int H,
+                       int W, int n_iter, int norm_type, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    return cspn2d_forward_f32_algo(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, CSPN_ALGO_AUTO, ws,
+                                   ws_bytes, stream);
+}
+
+size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    return stepwise3d_workspace(B, D, H, W, n_iter);
+}
+
+int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse, float* out, int B, int D, int H,
+                       int W, int n_iter, int norm_type, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d D=%d H=%d W=%d", B, D, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if ((long long)B * D * H * W > 0x7fffffffLL / 27) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    size_t need = n_iter == 0 ? 0 : stepwise3d_workspace(B, D, H, W, n_iter);
+    if (int e = check_common(gate, feat, out, n_iter, norm_type, ws, ws_bytes, need)) return e;
+    if (n_iter == 0) {
+        hipError_t e = hipMemcpyAsync(out, feat, sizeof(float) * (size_t)B * D * H * W, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+    }
+    return stepwise3d_forward(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, ws, st);
+}
+
+}  // extern "C"

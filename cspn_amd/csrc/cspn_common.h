@@ -1,0 +1,41 @@
+// cspn_common.h -- shared declarations of libcspn_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/cspn_amd.h"
+
+namespace cspn {
+
+// Neighbour offsets of the eight affinity channels, derived from the ZeroPad2d
+// tuples at reference cspn_pytorch/models/cspn.py:105-128 (dy = 1-top, dx = 1-left):
+// channel k couples output pixel p with neighbour p + (DY[k], DX[k]), and -- because
+// the reference pads the affinity planes with the SAME tuples as the depth
+// (cspn.py:149-167) -- its weight is read AT THE NEIGHBOUR ("neighbour-sited").
+__host__ __device__ constexpr int dy2(int k) { return k < 3 ? 1 : (k < 5 ? 0 : -1); }
+__host__ __device__ constexpr int dx2(int k) {
+    return (k == 0 || k == 3 || k == 5) ? 1 : ((k == 1 || k == 6) ? 0 : -1);
+}
+
+// sign() of reference cspn.py:64 (NaN stays NaN like torch.sign -> here NaN compares false -> s itself)
+__device__ __forceinline__ float signf(float s) { return s > 0.f ? 1.f : (s < 0.f ? -1.f : s); }
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- stepwise path (one launch per iteration; general shapes) ----
+size_t stepwise2d_workspace(int B, int H, int W, int n_iter);
+int stepwise2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
+                       int n_iter, int norm, void* ws, hipStream_t st);
+size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter);
+int stepwise3d_forward(const float* g, const float* feat, const float* sparse, float* out, int B, int D, int H,
+                       int W, int n_iter, int norm, void* ws, hipStream_t st);
+
+// ---- fused path (all iterations in one launch; time-skewed wave ring) ----
+bool fused2d_supported(int B, int H, int W, int n_iter);
+size_t fused2d_workspace(int B, int H, int W, int n_iter);
+int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
+                    int n_iter, int norm, void* ws, hipStream_t st);
+
+}  // namespace cspn

@@ -1,0 +1,98 @@
+"""Functional front-end over the C ABI: tensors in, tensor out, work enqueued on
+torch's current HIP stream.  PyTorch is plumbing here (device memory + streams);
+all arithmetic happens in libcspn_amd.so."""
+import torch
+
+from . import _lib
+
+
+def _prep(t, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise _lib.CspnError(
+            "cspn_amd: %s is on %s; the engine is GPU-only (hand-written HIP for gfx950) and has no CPU path"
+            % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t.contiguous()
+
+
+def _workspace(nbytes, device):
+    # torch's caching allocator: stream-ordered reuse is safe, base is >=512-B aligned
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+def cspn2d_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum", algo="auto"):
+    """All n_iter steps of reference cspn_pytorch/models/cspn.py:42-83 in the HIP engine.
+
+    guidance [B,8,H,W], blur_depth [B,1,H,W], sparse_depth [B,1,H,W] or None -> [B,1,H,W]."""
+    lib = _lib.load()
+    if guidance.dim() != 4 or guidance.shape[1] != 8:
+        raise ValueError("guidance must be [B,8,H,W], got %s" % (tuple(guidance.shape),))
+    B, _, H, W = guidance.shape
+    g = _prep(guidance, "guidance")
+    h = _prep(blur_depth, "blur_depth", (B, 1, H, W))
+    s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
+    if h.device != g.device or (s is not None and s.device != g.device):
+        raise ValueError("all tensors must live on the same device")
+    out = torch.empty_like(h)
+    if B == 0:
+        return out
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                         out.data_ptr(), B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                         _lib.ALGOS[algo], ws.data_ptr(), ws_bytes, stream)
+    _lib.check(rc, "cspn2d_forward_f32")
+    return out
+
+
+def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
+    """gate [B,26,D,H,W], feat [B,1,D,H,W] -> [B,1,D,H,W]; n_iter fused 3x3x3 propagation steps."""
+    lib = _lib.load()
+    if gate.dim() != 5 or gate.shape[1] != 26:
+        raise ValueError("gate must be [B,26,D,H,W], got %s" % (tuple(gate.shape),))
+    B, _, D, H, W = gate.shape
+    g = _prep(gate, "gate")
+    h = _prep(feat, "feat", (B, 1, D, H, W))
+    s = _prep(sparse, "sparse", (B, 1, D, H, W)) if sparse is not None else None
+    out = torch.empty_like(h)
+    if B == 0:
+        return out
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn3d_workspace_bytes(B, D, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        rc = lib.cspn3d_forward_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                    out.data_ptr(), B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                    ws.data_ptr(), ws_bytes, stream)
+    _lib.check(rc, "cspn3d_forward_f32")
+    return out
+
+
+def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
+    """Mirror of fluid.layers.affinity_propagate (reference cspn_paddle/demo.py:41-43,50-52;
+    contract cspn_paddle/README.md:54-56): input [N,C,...], gate_weight [N,3**d-1,...] already
+    normalised over the channel dim by the caller, shared across the C input channels.
+    d = 2 or 3.  n_iter > 1 fuses that many chained calls (demo.py:39,50)."""
+    if kernel_size != 3:
+        raise ValueError("only kernel_size == 3 is supported (reference cspn_paddle/demo.py:90)")
+    d = input.dim() - 2
+    if d not in (2, 3):
+        raise ValueError("input must be [N,C,H,W] or [N,C,D,H,W]")
+    if gate_weight.shape[1] != 3 ** d - 1:
+        raise ValueError("gate_weight must have %d channels" % (3 ** d - 1))
+    N, C = input.shape[:2]
+    outs = []
+    for c in range(C):  # gates shared across channels (README.md:56)
+        x = input[:, c:c + 1].contiguous()
+        if d == 2:
+            outs.append(cspn2d_forward(gate_weight, x, None, n_iter, "none"))
+        else:
+            outs.append(cspn3d_forward(gate_weight, x, None, n_iter, "none"))
+    return outs[0] if C == 1 else torch.cat(outs, 1)

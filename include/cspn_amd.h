@@ -1,0 +1,85 @@
+/*
+ * cspn_amd.h -- C ABI of the MI355X-native CSPN propagation engine (libcspn_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of XinJCheng/CSPN:
+ * Affinity_Propagate (reference: cspn_pytorch/models/cspn.py:14-83) and the
+ * 3x3x3 / pre-normalised-gate call site of the Paddle demo
+ * (reference: cspn_paddle/demo.py:41-43,50-52).  Plain pointers and sizes only,
+ * no torch types.  The binding a reference maintainer adds is ~25 lines of
+ * ctypes; cspn_amd/cspn.py is that binding, packaged.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32, contiguous NCHW / NCDHW) valid on
+ *     the current HIP device; the call only ENQUEUES work on `stream` and returns
+ *     (no hipDeviceSynchronize, no allocation, no global mutable state: safe to
+ *     call from several host threads, cf. nn.DataParallel at reference
+ *     cspn_pytorch/eval.py:117);
+ *   - inputs are never written; `out` must not alias an input;
+ *   - return 0 on success, a negative CSPN_E_* code on argument errors, or a
+ *     positive hipError_t; cspn_last_error() gives a thread-local message;
+ *   - `workspace` must hold cspn{2,3}d_workspace_bytes(...) bytes, 256-B aligned,
+ *     and must stay untouched until the enqueued work has finished.
+ */
+#ifndef CSPN_AMD_H
+#define CSPN_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSPN_ABI_VERSION 1
+
+/* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
+typedef void* cspn_stream_t;
+
+/* norm_type: reference cspn_pytorch/models/cspn.py:19,36 ('8sum' | '8sum_abs');
+ * NONE = gates are used as given, centre-sited, no centre term -- the contract of
+ * fluid.layers.affinity_propagate (reference cspn_paddle/README.md:54: "should be
+ * normalized in the channel dimension" by the caller, cspn_paddle/demo.py:47-49). */
+enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2 };
+
+/* algo: AUTO picks the fused single-launch kernel whenever the shape allows it. */
+enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2 };
+
+enum {
+    CSPN_E_BADARG = -1,   /* null pointer, non-positive size, unknown enum      */
+    CSPN_E_WORKSPACE = -2, /* workspace too small or misaligned                  */
+    CSPN_E_UNSUPPORTED = -3 /* algo explicitly requested but shape not supported */
+};
+
+int cspn_abi_version(void);
+const char* cspn_last_error(void);
+
+/* ---- 2D: replaces Affinity_Propagate.forward, reference cspn.py:42-83 -------
+ * (affinity_normalization :85-144, pad_blur_depth :147-172, sum_conv :44-53 and
+ * the elementwise tail :70-81 are all inside this one call)
+ *   guidance [B,8,H,W]  raw affinities as the backbone emits them (cspn.py:42)
+ *   blur     [B,1,H,W]  coarse depth, also the H_0 of the centre term (cspn.py:58,76)
+ *   sparse   [B,1,H,W]  or NULL; only its sign is used (cspn.py:64,81)
+ *   out      [B,1,H,W]
+ *   n_iter   = prop_time (cspn.py:31,66); 0 copies blur to out                  */
+size_t cspn2d_workspace_bytes(int B, int H, int W, int n_iter);
+int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sparse, float* out,
+                       int B, int H, int W, int n_iter, int norm_type,
+                       void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+/* same, with an explicit kernel choice (tests and bench use it to A/B the paths) */
+int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const float* sparse, float* out,
+                            int B, int H, int W, int n_iter, int norm_type, int algo,
+                            void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+/* which kernel AUTO would run for this shape: CSPN_ALGO_STEPWISE or CSPN_ALGO_FUSED */
+int cspn2d_auto_algo(int B, int H, int W, int n_iter);
+
+/* ---- 3D: replaces n_iter chained fluid.layers.affinity_propagate calls,
+ * reference cspn_paddle/demo.py:41-43,50-52 (kernel_size == 3 only, demo.py:90)
+ *   gate [B,26,D,H,W], feat [B,1,D,H,W], sparse [B,1,D,H,W] or NULL, out [B,1,D,H,W] */
+size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter);
+int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse, float* out,
+                       int B, int D, int H, int W, int n_iter, int norm_type,
+                       void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSPN_AMD_H */

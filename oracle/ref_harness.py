@@ -1,0 +1,43 @@
+"""Runs the UNMODIFIED reference module on CPU tensors.  Authoring-container only:
+/root/reference does not exist on the GPU box, so nothing that runs there may
+import this file.  Used by tests/golden/make_golden.py (fixture generation) and
+by tests/test_oracle.py::test_oracle_vs_live_reference (skipped when absent).
+
+The reference hard-codes `.cuda()` at cspn.py:50; we replace torch.Tensor.cuda
+with identity *around the call* (the reference file itself is untouched)."""
+import contextlib
+import importlib.util
+import os
+
+import torch
+
+REF_CSPN = "/root/reference/cspn_pytorch/models/cspn.py"
+
+
+def available():
+    return os.path.exists(REF_CSPN)
+
+
+def load_reference_module():
+    spec = importlib.util.spec_from_file_location("_reference_cspn", REF_CSPN)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@contextlib.contextmanager
+def cuda_is_identity():
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda = orig
+
+
+def reference_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum"):
+    """-> torch.float32 [B,1,H,W] computed by /root/reference/cspn_pytorch/models/cspn.py:42-83."""
+    ref = load_reference_module()
+    m = ref.Affinity_Propagate(n_iter, 3, norm_type)
+    with torch.no_grad(), cuda_is_identity():
+        return m(guidance, blur_depth, sparse_depth)

@@ -1,0 +1,72 @@
+"""CPU, gloo, world_size 2: the multi-GPU harness around the hot path (sharding, one-time
+flat broadcast of backbone weights, result gather).  The propagation itself needs no
+collective; on the GPU box the same code runs with backend "nccl" (= RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cspn_amd import dist as cd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)  # different init per rank before the broadcast
+        net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 8, 1))
+        nbytes = cd.broadcast_module_(net, src=0)
+        flat = torch.cat([p.detach().reshape(-1).float() for p in list(net.parameters()) + list(net.buffers())])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        same = bool(torch.equal(flat, ref))
+        # batch sharding: 7 samples over 2 ranks -> 4 + 3, contiguous, disjoint, covering
+        lo, hi = cd.shard_range(7, rank, world)
+        x = torch.arange(7.0).view(7, 1, 1, 1)
+        (mine,) = cd.shard_batch([x], rank, world)
+        # equal shards + gather: 6 samples
+        y = torch.arange(6.0).view(6, 1, 1, 1)
+        (part,) = cd.shard_batch([y], rank, world)
+        full = cd.gather_outputs(part * 2.0)
+        q.put((rank, same, nbytes, lo, hi, mine.flatten().tolist(), full.flatten().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_broadcast_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, same0, nb0, lo0, hi0, mine0, full0), (r1, same1, nb1, lo1, hi1, mine1, full1) = res
+    assert same0 and same1 and nb0 == nb1 > 0
+    assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)
+    assert mine0 == [0, 1, 2, 3] and mine1 == [4, 5, 6]
+    assert full0 == full1 == [0, 2, 4, 6, 8, 10]
+
+
+def test_shard_range_covers_everything():
+    for total in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [cd.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,217 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle, the
+committed golden vectors of the reference, and size-independent properties at
+BASELINE.json's full sizes.  Tolerance: 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import cspn_amd
+from cspn_amd import _lib
+from helpers import RTOL, make_inputs, rel_err
+from oracle import cspn2d_oracle, cspn3d_oracle
+
+pytestmark = pytest.mark.gpu
+NORMS = {0: "8sum", 1: "8sum_abs"}
+DEV = "cuda:0"
+
+
+def _algos(B, H, W, N):
+    lib = cspn_amd.load()
+    algos = ["stepwise"]
+    if N > 0 and lib.cspn2d_auto_algo(B, H, W, N) == _lib.ALGOS["fused"]:
+        algos.append("fused")
+    return algos
+
+
+def _run(g, h, s, N, norm, algo):
+    out = cspn_amd.cspn2d_forward(g.to(DEV), h.to(DEV), None if s is None else s.to(DEV), N, norm, algo)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_library_is_loaded_and_gpu_present():
+    assert torch.cuda.is_available()
+    assert cspn_amd.load().cspn_abi_version() == 1
+
+
+def test_golden_vectors(golden):
+    for name, c in golden.items():
+        B, H, W, N, norm = [int(v) for v in c["meta"]]
+        g, h = torch.from_numpy(c["guidance"]), torch.from_numpy(c["blur"])
+        s = torch.from_numpy(c["sparse"]) if "sparse" in c else None
+        if N == 0:
+            continue
+        for algo in _algos(B, H, W, N):
+            err = rel_err(_run(g, h, s, N, NORMS[norm], algo), c["out"])
+            assert err <= RTOL, (name, algo, err)
+
+
+SHAPES = [
+    # B, H, W, N, norm, sparse
+    (1, 228, 304, 12, "8sum", False),      # BASELINE config 1 shape
+    (2, 228, 304, 24, "8sum", True),       # config 2 shape (reduced batch; full batch below)
+    (1, 304, 1216, 24, "8sum", True),      # KITTI shape
+    (1, 304, 1216, 24, "8sum_abs", True),
+    (2, 37, 53, 24, "8sum", True),         # odd sizes, W not a multiple of 4
+    (1, 5, 300, 24, "8sum_abs", False),    # short and wide
+    (1, 300, 6, 24, "8sum", True),         # tall and narrow
+    (3, 64, 256, 7, "8sum", True),         # exactly one band wide
+    (1, 65, 260, 24, "8sum", True),        # just over one band
+    (1, 100, 516, 30, "8sum", True),       # n_iter > 24
+    (1, 1, 1, 3, "8sum", False),           # 1x1 -> NaN (no in-range neighbour)
+    (2, 2, 2, 2, "8sum_abs", True),
+    (1, 40, 1216, 1, "8sum", True),
+    (5, 48, 128, 24, "8sum", True),
+]
+
+
+@pytest.mark.parametrize("B,H,W,N,norm,sp", SHAPES)
+def test_parity_vs_oracle(B, H, W, N, norm, sp):
+    g, h, s = make_inputs(B, H, W, seed=B * 1000 + H + W + N, sparse=sp, neg=sp, depth_scale=80.0)
+    ref = cspn2d_oracle(g, h, s, N, norm)
+    for algo in _algos(B, H, W, N):
+        err = rel_err(_run(g, h, s, N, norm, algo), ref)
+        assert err <= RTOL, (algo, err)
+
+
+def test_nan_semantics_zero_guidance():
+    g, h, s = make_inputs(1, 40, 64, seed=9)
+    g[:, :, 10:17, 20:29] = 0.0  # 0/0 at cspn.py:138
+    ref = cspn2d_oracle(g, h, s, 3)
+    assert np.isnan(ref).sum() > 0
+    for algo in _algos(1, 40, 64, 3):
+        assert rel_err(_run(g, h, s, 3, "8sum", algo), ref) <= RTOL
+
+
+def test_module_call_and_stream_semantics():
+    g, h, s = make_inputs(2, 60, 96, seed=21)
+    m = cspn_amd.Affinity_Propagate(24, 3, "8sum").to(DEV)
+    gd, hd, sd = g.to(DEV), h.to(DEV), s.to(DEV)
+    g0, h0 = gd.clone(), hd.clone()
+    with torch.no_grad():
+        out = m(gd, hd, sd)
+        out6 = m(gd, hd, sd, n_iter=6)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out_side = m(gd, hd, sd)
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert out.shape == (2, 1, 60, 96) and out.device == gd.device
+    assert torch.equal(gd, g0) and torch.equal(hd, h0)  # inputs not mutated
+    assert rel_err(out.cpu().numpy(), cspn2d_oracle(g, h, s, 24)) <= RTOL
+    assert rel_err(out6.cpu().numpy(), cspn2d_oracle(g, h, s, 6)) <= RTOL
+    assert torch.equal(out, out_side)  # deterministic, stream-agnostic
+    assert list(m.state_dict().keys()) == []
+    assert m(gd, hd, sd, n_iter=0) is hd
+
+
+def test_noncontiguous_inputs():
+    g, h, s = make_inputs(2, 33, 40, seed=4)
+    gd = g.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)  # NHWC-strided view
+    out = cspn_amd.cspn2d_forward(gd, h.to(DEV), s.to(DEV), 5)
+    assert rel_err(out.cpu().numpy(), cspn2d_oracle(g, h, s, 5)) <= RTOL
+
+
+# ---- BASELINE.json full sizes: oracle where it finishes in seconds, properties everywhere ----
+
+def _config_inputs(B, H, W, scale, sparse, seed0=1000):
+    gs, hs, ss = [], [], []
+    for i in range(B):  # per-image seeding: any sharding sees identical data
+        gen = torch.Generator().manual_seed(seed0 + i)
+        gs.append(torch.randn(8, H, W, generator=gen))
+        hs.append(torch.rand(1, H, W, generator=gen) * scale)
+        if sparse:
+            m = (torch.rand(1, H, W, generator=gen) < 500.0 / (H * W)).float()
+            ss.append(m * (torch.rand(1, H, W, generator=gen) * scale + 0.1))
+    return torch.stack(gs), torch.stack(hs), (torch.stack(ss) if sparse else None)
+
+
+@pytest.mark.parametrize("name,B,H,W,scale,sparse", [("config2", 16, 228, 304, 10.0, True),
+                                                     ("config3_per_gpu", 8, 304, 1216, 80.0, False),
+                                                     ("config4", 32, 304, 1216, 80.0, True)])
+def test_full_size_configs(name, B, H, W, scale, sparse):
+    g, h, s = _config_inputs(B, H, W, scale, sparse)
+    gd, hd = g.to(DEV), h.to(DEV)
+    sd = s.to(DEV) if sparse else None
+    outs = {}
+    for algo in _algos(B, H, W, 24):
+        outs[algo] = cspn_amd.cspn2d_forward(gd, hd, sd, 24, "8sum", algo)
+    torch.cuda.synchronize()
+    # oracle on a sample of the batch (first, middle, last image)
+    idx = sorted({0, B // 2, B - 1})
+    ref = cspn2d_oracle(g[idx], h[idx], None if s is None else s[idx], 24, "8sum")
+    for algo, out in outs.items():
+        assert rel_err(out[idx].cpu().numpy(), ref) <= RTOL, (name, algo)
+        # properties over the WHOLE batch
+        if sparse:
+            m = sd > 0
+            assert torch.equal(out[m], hd[m])  # pinned pixels equal blur exactly (cspn.py:81)
+        assert torch.isfinite(out).all()
+        # linearity in the depth (fixed guidance/mask): f(2a - b/2) = 2 f(a) - f(b)/2
+        h2 = torch.roll(hd, 1, 0)
+        o2 = cspn_amd.cspn2d_forward(gd, h2, sd, 24, "8sum", algo)
+        o12 = cspn_amd.cspn2d_forward(gd, 2.0 * hd - 0.5 * h2, sd, 24, "8sum", algo)
+        lin = (o12 - (2.0 * out - 0.5 * o2)).abs().max() / out.abs().max()
+        assert float(lin) <= RTOL, (name, algo, float(lin))
+    if len(outs) == 2:  # the two HIP paths agree on every pixel of the batch
+        d = (outs["fused"] - outs["stepwise"]).abs().max() / outs["stepwise"].abs().max()
+        assert float(d) <= RTOL
+    # constant depth is a fixed point
+    const = torch.full_like(hd, 7.5)
+    oc = cspn_amd.cspn2d_forward(gd, const, None, 24, "8sum_abs")
+    assert float((oc - 7.5).abs().max()) <= 7.5 * RTOL
+
+
+# ---- 3D ----
+
+@pytest.mark.parametrize("B,D,H,W,N,norm,sp", [(1, 4, 9, 11, 5, "8sum_abs", False), (2, 6, 10, 37, 12, "8sum", True),
+                                               (1, 3, 8, 64, 3, "none", False), (1, 1, 1, 1, 2, "8sum", False)])
+def test_3d_parity_vs_oracle(B, D, H, W, N, norm, sp):
+    gen = torch.Generator().manual_seed(D * 100 + H)
+    g = torch.randn(B, 26, D, H, W, generator=gen) if norm == "8sum" else torch.rand(B, 26, D, H, W, generator=gen)
+    if norm == "none":
+        g = g / g.sum(1, keepdim=True)  # cspn_paddle/demo.py:47-49
+    h = torch.rand(B, 1, D, H, W, generator=gen)
+    s = None
+    if sp:
+        s = (torch.rand(B, 1, D, H, W, generator=gen) < 0.05).float() * h
+    out = cspn_amd.cspn3d_forward(g.to(DEV), h.to(DEV), None if s is None else s.to(DEV), N, norm)
+    assert rel_err(out.cpu().numpy(), cspn3d_oracle(g, h, s, N, norm)) <= RTOL
+
+
+def test_3d_config5_shape_properties():
+    """BASELINE config 5: 32x160x608, batch 4, 12 iters, demo-style non-negative gates."""
+    B, D, H, W = 4, 32, 160, 608
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=DEV)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device=DEV)
+    out = cspn_amd.cspn3d_forward(g, h, None, 12, "8sum_abs")
+    assert torch.isfinite(out).all()
+    # convex combination of neighbours: stays inside the input range
+    assert float(out.min()) >= -1e-5 and float(out.max()) <= 1.0 + 1e-5
+    const = torch.full_like(h, 3.0)
+    oc = cspn_amd.cspn3d_forward(g, const, None, 12, "8sum_abs")
+    assert float((oc - 3.0).abs().max()) <= 3.0 * RTOL
+    # oracle on one image at reduced depth would change the problem; instead check one sub-volume
+    # against the oracle by running both on an identical smaller crop
+    gc, hc = g[:1, :, :6, :24, :40].contiguous(), h[:1, :, :6, :24, :40].contiguous()
+    oc = cspn_amd.cspn3d_forward(gc, hc, None, 12, "8sum_abs")
+    assert rel_err(oc.cpu().numpy(), cspn3d_oracle(gc.cpu(), hc.cpu(), None, 12, "8sum_abs")) <= RTOL
+
+
+def test_paddle_style_affinity_propagate():
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 3, 5, 12, 16, generator=gen)  # C=3 channels share the gates (README.md:56)
+    g = torch.rand(2, 26, 5, 12, 16, generator=gen)
+    g = g / g.sum(1, keepdim=True)
+    out = cspn_amd.affinity_propagate(x.to(DEV), g.to(DEV), kernel_size=3)
+    assert out.shape == x.shape
+    for c in range(3):
+        ref = cspn3d_oracle(g, x[:, c:c + 1], None, 1, "none")
+        assert rel_err(out[:, c:c + 1].cpu().numpy(), ref) <= RTOL
+    x2 = torch.rand(2, 1, 20, 24, generator=gen)
+    g2 = torch.rand(2, 8, 20, 24, generator=gen)
+    g2 = g2 / g2.sum(1, keepdim=True)
+    o2 = cspn_amd.affinity_propagate(x2.to(DEV), g2.to(DEV), n_iter=4)
+    assert rel_err(o2.cpu().numpy(), cspn2d_oracle(g2, x2, None, 4, "none")) <= RTOL
