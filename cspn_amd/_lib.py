@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcspn_amd.so")
+LIB_PATH = os.environ.get("CSPN_AMD_LIB") or os.path.join(_HERE, "libcspn_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}

@@ -1,10 +1,561 @@
-// placeholder until the time-skewed fused kernel lands
+// cspn2d_fused.hip -- all n_iter propagation steps of Affinity_Propagate.forward
+// (reference cspn_pytorch/models/cspn.py:42-83, with affinity_normalization :85-144,
+// pad_blur_depth :147-172, sum_conv :44-53 and the tail :70-81) in ONE launch for gfx950.
+//
+// "Time-skewed wave ring" (executable specification: tools/tsw_model.py):
+//   * a workgroup = 8 waves streams a 256-column band of the image top -> bottom;
+//   * every lane owns 4 adjacent columns, held as two float2 pairs (c0,c2),(c1,c3) so that the
+//     inner loop is v_pk_fma_f32 (2 FMAs per VALU slot; x+-1 inside a lane is the OTHER pair,
+//     across lanes it is a DPP wave_shr/wave_shl move);
+//   * every wave keeps 4 consecutive image rows resident: 9 folded coefficients per pixel
+//     (8 normalised, mask-folded affinities + the centre/mask constant) and two partial
+//     accumulators -- 176 VGPRs of state, weights never leave registers;
+//   * the 32 resident rows form a ring; row q enters at step phi(q) = 3*(q/4) + q%4 and
+//     advances one CSPN iteration per step, so rows inside a wave sit on a 1-level staircase
+//     and the first/last row of neighbouring waves sit at the SAME level ("flat spot"): the
+//     only cross-wave traffic is two 1 KB boundary rows per wave per step through LDS, consumed
+//     one step later (one s_barrier per step, double buffered);
+//   * "push" form: a completed row value V immediately adds its three contributions
+//     (below / self / above taps) to the accumulators of rows r-1, r, r+1, so shifted copies of
+//     V are transient and no second copy of the depth is stored;
+//   * affinity normalisation, centre term and sparse-mask folding ("cooking") are done by all
+//     512 threads, one pixel each, two events every three steps, from global loads issued one
+//     event earlier; cooked rows reach the owning wave through LDS (9 planes + H0 ring);
+//   * all 24 iterations need each input byte once: 40 B/pixel (44 with sparse) of HBM traffic.
+#include <type_traits>
+
 #include "cspn_common.h"
+
 namespace cspn {
-bool fused2d_supported(int, int, int, int) { return false; }
-size_t fused2d_workspace(int, int, int, int) { return 0; }
-int fused2d_forward(const float*, const float*, const float*, float*, int, int, int, int, int, void*, hipStream_t) {
-    set_error("fused kernel not built");
-    return CSPN_E_UNSUPPORTED;
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int NW = 8;        // waves per workgroup
+constexpr int R = 4;         // resident rows (slots) per wave
+constexpr int LV = 24;       // NW*(R-1): iterations fused per pass
+constexpr int BW = 256;      // band width in pixels: 64 lanes x 4 columns
+constexpr int NT = NW * 64;  // threads per workgroup
+constexpr int MIN_ROWS_PER_WG = 128;
+
+struct Lds {
+    float bnd[2][NW][2][BW];  // [step parity][wave][0: top row (slot 0) | 1: bottom row (slot 3)]
+    float cook[4][9][BW];     // folded coefficients of stream row q in cook[q & 3]
+    float h0[8][BW];          // level-0 value of stream row q in h0[q & 7]
+    int hdr[4][4];            // per cooked row: active, out offset (or -1), own lo, own hi (band relative)
+    int meta[NW][R][4];       // the same record for the row currently held by (wave, slot)
+};
+
+// ---- lane-crossing moves (DPP, whole-wave shift by one lane; edge lanes read 0) -------------
+__device__ __forceinline__ float dpp_shr1(float v) {  // lane i <- lane i-1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
+__device__ __forceinline__ float dpp_shl1(float v) {  // lane i <- lane i+1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// A row value as seen by its consumers: p0 = (c0,c2), p1 = (c1,c3) and the two lane-crossing
+// pairs xl = (c3 of lane-1, c1), xr = (c2, c0 of lane+1).
+struct Shift { f2 p0, p1, xl, xr; };
+__device__ __forceinline__ Shift mk_shift(f2 p0, f2 p1) {
+    Shift s;
+    s.p0 = p0;
+    s.p1 = p1;
+    s.xl = f2{dpp_shr1(p1.y), p1.x};
+    s.xr = f2{p0.y, dpp_shl1(p0.x)};
+    return s;
+}
+// three taps KR (dx=+1), KM (dx=0), KL (dx=-1) of one neighbour row
+template <int KR, int KM, int KL>
+__device__ __forceinline__ void push3(const f2 (&w)[9][2], const Shift& s, f2& a0, f2& a1) {
+    a0 = pkfma(w[KR][0], s.p1, a0);
+    a1 = pkfma(w[KR][1], s.xr, a1);
+    a0 = pkfma(w[KM][0], s.p0, a0);
+    a1 = pkfma(w[KM][1], s.p1, a1);
+    a0 = pkfma(w[KL][0], s.xl, a0);
+    a1 = pkfma(w[KL][1], s.p0, a1);
+}
+// channel k <-> (dy,dx): 0 (+1,+1) 1 (+1,0) 2 (+1,-1) | 3 (0,+1) 4 (0,-1) | 5 (-1,+1) 6 (-1,0) 7 (-1,-1)
+__device__ __forceinline__ void push_below(const f2 (&w)[9][2], const Shift& s, f2& a0, f2& a1) { push3<0, 1, 2>(w, s, a0, a1); }
+__device__ __forceinline__ void push_above(const f2 (&w)[9][2], const Shift& s, f2& a0, f2& a1) { push3<5, 6, 7>(w, s, a0, a1); }
+__device__ __forceinline__ void push_self(const f2 (&w)[9][2], const Shift& s, f2& a0, f2& a1) {
+    a0 = pkfma(w[3][0], s.p1, a0);
+    a1 = pkfma(w[3][1], s.xr, a1);
+    a0 = pkfma(w[4][0], s.xl, a0);
+    a1 = pkfma(w[4][1], s.p0, a1);
+}
+
+// band column x -> position inside the LDS row: each lane's 4 columns are stored (c0,c2,c1,c3)
+// so one ds_read_b128 yields the two register pairs with no shuffles.
+__device__ __forceinline__ int perm4(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
+
+__device__ __forceinline__ void wg_barrier() {
+#if defined(CSPN_DBG_SYNCTHREADS)
+    __syncthreads();
+#elif defined(CSPN_DBG_FENCE_BARRIER)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    // LDS-only barrier: must not drain the in-flight global prefetch (vmcnt) like __syncthreads() would
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// ---- the stream of rows a workgroup processes ------------------------------------------------
+struct Geo {
+    int B, H, W, n_iter, nb, halo;  // nb bands per image, horizontal halo (multiple of 4)
+};
+#ifdef CSPN_DBG_CHECK
+__device__ int g_dbg[32];
+__device__ int g_trace[2048 * 8];
+__device__ int g_ntrace;
+#define DBG_CHECK(cond, code, a, b, c, d)                                                  \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            if (atomicAdd(&g_dbg[0], 1) == 0) {                                            \
+                g_dbg[1] = (code); g_dbg[2] = (a); g_dbg[3] = (b); g_dbg[4] = (c); g_dbg[5] = (d); \
+                g_dbg[6] = blockIdx.x; g_dbg[7] = threadIdx.x;                             \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+#else
+#define DBG_CHECK(cond, code, a, b, c, d) do { } while (0)
+#endif
+struct RowInfo {
+    int active;   // 0: separator / past-the-end row (stays exactly zero)
+    int b, y, p0; // image, image row, first physical column of the band
+    int outoff;   // element offset of out[b][0][y][p0], or -1 when the row is only halo
+    int lo, hi;   // owned columns, band relative
+};
+__device__ __forceinline__ void band_of(const Geo& g, int bi, int& p0, int& lo, int& hi) {
+    if (g.W <= BW) { p0 = 0; lo = 0; hi = g.W; return; }
+    if (bi == 0) { p0 = 0; lo = 0; }
+    else { lo = (BW - g.halo) + (bi - 1) * (BW - 2 * g.halo); p0 = lo - g.halo; }
+    hi = (p0 + BW >= g.W) ? g.W : p0 + BW - g.halo;
+}
+struct Cursor {
+    int r_next, r_end;  // [r_next, r_end): still unopened part of this workgroup's share of B*nb*H rows
+    int in_seg, pending;
+    int b, p0, lo, hi, y0, y1, ye, y;
+    __device__ __forceinline__ void init(int r0, int r1) {
+        r_next = r0; r_end = r1; in_seg = 0; pending = r0 < r1;
+        b = p0 = lo = hi = y0 = y1 = ye = y = 0;
+    }
+    __device__ __forceinline__ void open(const Geo& g) {
+        const int u = r_next / g.H;
+        y0 = r_next - u * g.H;
+        y1 = min(g.H, y0 + (r_end - r_next));
+        r_next += y1 - y0;
+        b = u / g.nb;
+        band_of(g, u - b * g.nb, p0, lo, hi);
+        y = max(0, y0 - g.n_iter);
+        ye = min(g.H, y1 + g.n_iter);
+        in_seg = 1; pending = 0;
+    }
+    __device__ __forceinline__ RowInfo next(const Geo& g) {
+        RowInfo r; r.active = 0; r.b = 0; r.y = 0; r.p0 = 0; r.outoff = -1; r.lo = 0; r.hi = 0;
+        if (in_seg && y >= ye) {  // segment exhausted: emit a separator (or idle rows at the very end)
+            in_seg = 0; pending = r_next < r_end;
+            return r;
+        }
+        if (!in_seg) {
+            if (!pending) return r;
+            open(g);
+        }
+        r.active = 1; r.b = b; r.y = y; r.p0 = p0; r.lo = lo - p0; r.hi = hi - p0;
+        r.outoff = (y >= y0 && y < y1) ? ((b * g.H + y) * g.W + p0) : -1;
+        ++y;
+        return r;
+    }
+};
+// number of stream rows of a share (segments + separators between them)
+__device__ __forceinline__ int stream_length(const Geo& g, int r0, int r1) {
+    int q = 0, r = r0;
+    while (r < r1) {
+        const int u = r / g.H, y0 = r - u * g.H, y1 = min(g.H, y0 + (r1 - r));
+        q += (min(g.H, y1 + g.n_iter) - max(0, y0 - g.n_iter)) + (r > r0 ? 1 : 0);
+        r += y1 - y0;
+    }
+    return q;
+}
+
+// ---- cooking: per pixel normalise + fold (cspn.py:85-144, :76, :81) ---------------------------
+struct Pend {  // one pixel's raw inputs, loaded one cook event ahead
+    float g[8], blur, hin, sp;
+};
+
+template <int NORM, bool SPARSE, bool HIN>
+__device__ __forceinline__ void issue_loads(Pend& p, const RowInfo& ri, int x, const Geo& g, const float* __restrict__ gd,
+                                            const float* __restrict__ blur, const float* __restrict__ hin,
+                                            const float* __restrict__ sparse) {
+    const int HW = g.H * g.W;
+    const int xg = ri.p0 + x;  // image column
+    const bool in = ri.active && xg < g.W;
+    const float* gb = gd + (size_t)ri.b * 8 * HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = 0.f;
+        if (NORM == CSPN_NORM_NONE) {
+            if (in) v = gb[k * HW + ri.y * g.W + xg];
+        } else {
+            const int yy = ri.y + dy2(k), xb = x + dx2(k), xx = xg + dx2(k);
+            // the band only sees its own 256 columns: neighbours outside read 0 (halo pixels, never output)
+            if (in && yy >= 0 && yy < g.H && xb >= 0 && xb < BW && xx < g.W) {
+                DBG_CHECK(ri.b >= 0 && ri.b < g.B && yy * g.W + xx >= 0 && yy * g.W + xx < HW, 1, ri.b, yy, xx, k);
+#ifdef CSPN_DBG_CHECK
+                if (ri.b >= 0 && ri.b < g.B && yy * g.W + xx >= 0 && yy * g.W + xx < HW)
+#endif
+                v = gb[k * HW + yy * g.W + xx];
+            }
+        }
+        p.g[k] = v;
+    }
+    const int off = (ri.b * g.H + ri.y) * g.W + xg;
+    DBG_CHECK(!in || (off >= 0 && off < g.B * HW && ri.y >= 0 && ri.y < g.H && ri.b >= 0 && ri.b < g.B), 2, ri.b, ri.y, xg, off);
+#ifdef CSPN_DBG_CHECK
+    const bool in_ok = in && off >= 0 && off < g.B * HW && ri.b >= 0 && ri.b < g.B;
+    p.blur = in_ok ? blur[off] : 0.f;
+    p.hin = HIN ? (in_ok ? hin[off] : 0.f) : p.blur;
+    p.sp = (SPARSE && in_ok) ? sparse[off] : 0.f;
+    return;
+#endif
+    p.blur = in ? blur[off] : 0.f;
+    p.hin = HIN ? (in ? hin[off] : 0.f) : p.blur;
+    p.sp = (SPARSE && in) ? sparse[off] : 0.f;
+}
+
+template <int NORM, bool SPARSE>
+__device__ __forceinline__ void cook_pixel(const Pend& p, const RowInfo& ri, int q, int x, int W, Lds& lds) {
+    float w[8], S = 0.f, c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        w[k] = (NORM == CSPN_NORM_8SUM_ABS) ? fabsf(p.g[k]) : p.g[k];
+        S += fabsf(w[k]);
+    }
+    // separator rows and columns right of the image carry all-zero inputs: make their coefficients
+    // exactly 0 (not 0/0) so they stay zero like the reference's ZeroPad2d border
+    if (!(ri.active && ri.p0 + x < W)) S = 1.f;
+    if (NORM == CSPN_NORM_NONE) {
+        c = 0.f;
+    } else {
+        const float inv = 1.0f / S;  // IEEE division; 0 * inf = NaN reproduces torch.div's 0/0 (cspn.py:138)
+        float sigma = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { w[k] *= inv; sigma += w[k]; }
+        c = (1.f - sigma) * p.blur;  // cspn.py:76
+    }
+    if (SPARSE) {  // cspn.py:64,81
+        const float m = signf(p.sp), om = 1.f - m;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] *= om;
+        c = om * c + m * p.blur;
+    }
+    const int px = perm4(x);
+    const int cb = q & 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds.cook[cb][k][px] = w[k];
+    lds.cook[cb][8][px] = c;
+    lds.h0[q & 7][px] = p.hin;
+}
+
+// ---- the kernel -------------------------------------------------------------------------------
+template <int NORM, bool SPARSE, bool HIN>
+__global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __restrict__ gd, const float* __restrict__ blur,
+                                                              const float* __restrict__ hin,
+                                                              const float* __restrict__ sparse, float* __restrict__ out,
+                                                              Geo geo) {
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // this workgroup's share of the B x bands x H row space
+    const long long total = (long long)geo.B * geo.nb * geo.H;
+    const int r0 = (int)(total * blockIdx.x / gridDim.x), r1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int Q = stream_length(geo, r0, r1);
+    if (Q == 0) return;
+    const int last_step = 3 * ((Q - 1) >> 2) + ((Q - 1) & 3) + geo.n_iter;
+
+    // ---- register-resident state ----
+    f2 Wt[R][9][2];     // folded coefficients of the 4 resident rows (Wt[j][8] = c')
+    f2 S[2][R][2];      // accumulators, S[step parity][slot][pair]
+    int act[R];                // 0: the slot holds a separator / nothing -> its value is pinned to 0
+    int cnt0 = (LV * 4 - 3 * wv) % LV;  // slot j is at phase (cnt0 - j) mod 24; 0 = injection step
+    int qgen = 0;              // generation: slot j takes stream row 4*(wv + 8*qgen) + j next
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Wt[j][k][0] = f2{0.f, 0.f}; Wt[j][k][1] = f2{0.f, 0.f}; }
+        S[0][j][0] = S[0][j][1] = S[1][j][0] = S[1][j][1] = f2{0.f, 0.f};
+        act[j] = 0;
+    }
+    for (int i = tid; i < 2 * NW * 2 * BW; i += NT) (&lds.bnd[0][0][0][0])[i] = 0.f;
+
+    // ---- cooking pipeline: event e cooks stream rows (2e-1, 2e); waves 0-3 take the first, 4-7 the second
+    const int crow = wv >> 2;  // which of the event's two rows this thread cooks
+    const int cx = tid & 255;  // its band column
+    Cursor cur;
+    cur.init(r0, r1);
+    Pend pend;
+    RowInfo pinfo;             // row the pending loads belong to
+    int pq;                    // its stream index
+    {   // event 0: rows (-1, 0)
+        RowInfo rb = cur.next(geo);
+        pinfo = rb; pq = crow ? 0 : -1;
+        if (!crow) pinfo.active = 0;
+        issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
+    }
+    int ev = 0;
+    auto cook_event = [&]() {
+        // consume the pending pixel (loaded one event ago) ...
+        if (pq >= 0) {
+            cook_pixel<NORM, SPARSE>(pend, pinfo, pq, cx, geo.W, lds);
+            if (cx == 0) {
+                lds.hdr[pq & 3][0] = pinfo.active; lds.hdr[pq & 3][1] = pinfo.outoff;
+                lds.hdr[pq & 3][2] = pinfo.lo; lds.hdr[pq & 3][3] = pinfo.hi;
+            }
+        }
+        // ... and issue the loads of the next event's rows
+        ++ev;
+        const RowInfo ra = cur.next(geo), rb = cur.next(geo);
+        pinfo = crow ? rb : ra;
+        pq = 2 * ev - 1 + crow;
+        issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
+    };
+    cook_event();  // cooks row 0, prefetches rows (1, 2)
+    wg_barrier();
+
+    int tau_cur = 0;
+#ifdef CSPN_DBG_CHECK
+    int dbg_tau = -1;
+#endif
+    // ---- per-slot events: zero inactive rows, retire (write level n_iter), inject the next stream row
+    auto slot_events = [&](auto JT, f2& v0, f2& v1, f2& n20, f2& n21) -> bool {
+        constexpr int j = decltype(JT)::value;
+        if (!act[j]) { v0 = f2{0.f, 0.f}; v1 = f2{0.f, 0.f}; }
+        const int cntj = cnt0 >= j ? cnt0 - j : cnt0 + LV - j;
+        // phase 0 = this slot's row completed level 24 and the next stream row enters.  (wave 7, slot 3) has
+        // phi = 24 == 0 (mod 24): its counter is also 0 at step 0, before its first row exists.
+        const bool inj = cntj == 0 && tau_cur >= 3 * wv + j;
+        const int lvl = cntj == 0 ? LV : cntj;
+        if (lvl == geo.n_iter && act[j]) {
+            const int outoffj = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][1]);
+            const int oloj = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][2]);
+            const int ohij = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][3]);
+            const int xb = 4 * lane;
+            if (outoffj >= 0 && xb >= oloj && xb < ohij) {
+                DBG_CHECK(outoffj + xb >= 0 && outoffj + xb + 3 < geo.B * geo.H * geo.W && oloj >= 0 && ohij <= BW, 3, outoffj, oloj, ohij, (j << 16) | cntj);
+#ifdef CSPN_DBG_CHECK
+                if (outoffj + xb >= 0 && outoffj + xb + 3 < geo.B * geo.H * geo.W)
+#endif
+                *reinterpret_cast<float4*>(out + (size_t)outoffj + xb) = make_float4(v0.x, v1.x, v0.y, v1.y);
+            }
+        }
+        if (inj) {
+            const int q = 4 * (wv + NW * qgen) + j;
+            const int cb = q & 3;
+            const int4 hd = *reinterpret_cast<const int4*>(&lds.hdr[cb][0]);
+            *reinterpret_cast<int4*>(&lds.meta[wv][j][0]) = hd;  // kept for this row's retirement (same wave: in order)
+            act[j] = __builtin_amdgcn_readfirstlane(hd.x);
+#ifdef CSPN_DBG_CHECK
+            if (blockIdx.x == 0 && lane == 0) {
+                const int t = atomicAdd(&g_ntrace, 1);
+                if (t < 2048) {
+                    g_trace[t * 8 + 0] = dbg_tau; g_trace[t * 8 + 1] = wv; g_trace[t * 8 + 2] = j; g_trace[t * 8 + 3] = q;
+                    g_trace[t * 8 + 4] = hd.x; g_trace[t * 8 + 5] = hd.y; g_trace[t * 8 + 6] = hd.z; g_trace[t * 8 + 7] = hd.w;
+                }
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(&lds.cook[cb][k][4 * lane]);
+                Wt[j][k][0] = f2{t.x, t.y};
+                Wt[j][k][1] = f2{t.z, t.w};
+            }
+            const float4 h = *reinterpret_cast<const float4*>(&lds.h0[q & 7][4 * lane]);
+            v0 = f2{h.x, h.y};
+            v1 = f2{h.z, h.w};
+            // accumulator of level 1: c' + self taps of H0(q) (+ above taps of H0(q-1), same wave)
+            n20 = Wt[j][8][0];
+            n21 = Wt[j][8][1];
+            const Shift s = mk_shift(v0, v1);
+            push_self(Wt[j], s, n20, n21);
+            if (j > 0) {
+                const float4 ha = *reinterpret_cast<const float4*>(&lds.h0[(q - 1) & 7][4 * lane]);
+                const Shift sa = mk_shift(f2{ha.x, ha.y}, f2{ha.z, ha.w});
+                push_above(Wt[j], sa, n20, n21);
+            }
+            if (j == R - 1) ++qgen;
+        }
+        return inj;
+    };
+
+    auto step = [&](auto PT) {
+        constexpr int PAR = decltype(PT)::value;
+        f2 (&N1)[R][2] = S[PAR];
+        f2 (&N2)[R][2] = S[PAR ^ 1];
+        const float4 tq = *reinterpret_cast<const float4*>(&lds.bnd[PAR ^ 1][(wv + NW - 1) & (NW - 1)][1][4 * lane]);
+        const float4 bq = *reinterpret_cast<const float4*>(&lds.bnd[PAR ^ 1][(wv + 1) & (NW - 1)][0][4 * lane]);
+        Shift s;
+        bool inj;
+        // received rows: above taps for slot 0 (prev block's bottom row), below taps for slot 3 (next block's top row)
+        s = mk_shift(f2{tq.x, tq.y}, f2{tq.z, tq.w});
+        push_above(Wt[0], s, N1[0][0], N1[0][1]);
+        s = mk_shift(f2{bq.x, bq.y}, f2{bq.z, bq.w});
+        push_below(Wt[3], s, N1[3][0], N1[3][1]);
+        // slot 3 completes
+        inj = slot_events(std::integral_constant<int, 3>{}, N1[3][0], N1[3][1], N2[3][0], N2[3][1]);
+        *reinterpret_cast<float4*>(&lds.bnd[PAR][wv][1][4 * lane]) = make_float4(N1[3][0].x, N1[3][0].y, N1[3][1].x, N1[3][1].y);
+        s = mk_shift(N1[3][0], N1[3][1]);
+        push_below(Wt[2], s, N1[2][0], N1[2][1]);
+        if (!inj) push_self(Wt[3], s, N2[3][0], N2[3][1]);
+        // slot 2 completes
+        inj = slot_events(std::integral_constant<int, 2>{}, N1[2][0], N1[2][1], N2[2][0], N2[2][1]);
+        s = mk_shift(N1[2][0], N1[2][1]);
+        push_below(Wt[1], s, N1[1][0], N1[1][1]);
+        if (!inj) push_self(Wt[2], s, N2[2][0], N2[2][1]);
+        N1[3][0] = Wt[3][8][0]; N1[3][1] = Wt[3][8][1];
+        push_above(Wt[3], s, N1[3][0], N1[3][1]);
+        // slot 1 completes
+        inj = slot_events(std::integral_constant<int, 1>{}, N1[1][0], N1[1][1], N2[1][0], N2[1][1]);
+        s = mk_shift(N1[1][0], N1[1][1]);
+        push_below(Wt[0], s, N1[0][0], N1[0][1]);
+        if (!inj) push_self(Wt[1], s, N2[1][0], N2[1][1]);
+        N1[2][0] = Wt[2][8][0]; N1[2][1] = Wt[2][8][1];
+        push_above(Wt[2], s, N1[2][0], N1[2][1]);
+        // slot 0 completes
+        inj = slot_events(std::integral_constant<int, 0>{}, N1[0][0], N1[0][1], N2[0][0], N2[0][1]);
+        *reinterpret_cast<float4*>(&lds.bnd[PAR][wv][0][4 * lane]) = make_float4(N1[0][0].x, N1[0][0].y, N1[0][1].x, N1[0][1].y);
+        s = mk_shift(N1[0][0], N1[0][1]);
+        if (!inj) {
+            N2[0][0] = Wt[0][8][0]; N2[0][1] = Wt[0][8][1];
+            push_self(Wt[0], s, N2[0][0], N2[0][1]);
+        }
+        N1[1][0] = Wt[1][8][0]; N1[1][1] = Wt[1][8][1];
+        push_above(Wt[1], s, N1[1][0], N1[1][1]);
+        cnt0 = (cnt0 + 1 == LV) ? 0 : cnt0 + 1;
+    };
+
+    int tau3 = 0;  // tau mod 3
+    for (int tau = 0; tau <= last_step; tau += 2) {
+        tau_cur = tau;
+#ifdef CSPN_DBG_CHECK
+        dbg_tau = tau;
+#endif
+        step(std::integral_constant<int, 0>{});
+        if (tau3 != 1) cook_event();
+        tau3 = tau3 == 2 ? 0 : tau3 + 1;
+        wg_barrier();
+        if (tau + 1 > last_step) break;
+        tau_cur = tau + 1;
+#ifdef CSPN_DBG_CHECK
+        dbg_tau = tau + 1;
+#endif
+        step(std::integral_constant<int, 1>{});
+        if (tau3 != 1) cook_event();
+        tau3 = tau3 == 2 ? 0 : tau3 + 1;
+        wg_barrier();
+    }
+}
+
+#ifdef CSPN_DBG_CHECK
+}  // namespace
+}  // namespace cspn
+extern "C" int cspn_debug_trace(int* dst, int* n) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(cspn::g_ntrace), sizeof(int));
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(cspn::g_trace), sizeof(int) * 2048 * 8);
+    int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(cspn::g_ntrace), &z, sizeof(int));
+    return (int)e;
+}
+extern "C" int cspn_debug_read(int* dst, int reset) {
+    hipDeviceSynchronize();
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(cspn::g_dbg), sizeof(int) * 32);
+    if (reset) { int z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(cspn::g_dbg), z, sizeof(z)); }
+    return (int)e;
+}
+namespace cspn {
+namespace {
+#endif
+
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
+int bands_of(int W, int halo) {
+    if (W <= BW) return 1;
+    int nb = 0, lo = 0;
+    while (lo < W) {
+        const int p0 = lo == 0 ? 0 : lo - halo;
+        lo = (p0 + BW >= W) ? W : p0 + BW - halo;
+        ++nb;
+    }
+    return nb;
+}
+
+template <int NORM, bool SPARSE>
+void launch_pass(bool hin_differs, int grid, hipStream_t st, const float* g, const float* blur, const float* hin,
+                 const float* sparse, float* out, const Geo& geo) {
+    if (hin_differs)
+        hipLaunchKernelGGL((cspn2d_fused_kernel<NORM, SPARSE, true>), dim3(grid), dim3(NT), 0, st, g, blur, hin, sparse, out, geo);
+    else
+        hipLaunchKernelGGL((cspn2d_fused_kernel<NORM, SPARSE, false>), dim3(grid), dim3(NT), 0, st, g, blur, hin, sparse, out, geo);
+}
+
+}  // namespace
+
+bool fused2d_supported(int B, int H, int W, int n_iter) {
+    return B > 0 && H > 0 && W > 0 && n_iter > 0 && (W % 4) == 0;
+}
+
+size_t fused2d_workspace(int B, int H, int W, int n_iter) {
+    // one ping buffer for n_iter > 24 (passes alternate between it and `out`)
+    return n_iter > LV ? (size_t)B * H * W * sizeof(float) : 0;
+}
+
+int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
+                    int n_iter, int norm, void* ws, hipStream_t st) {
+    if (((uintptr_t)out & 15u) != 0) { set_error("fused kernel needs a 16-byte aligned output"); return CSPN_E_UNSUPPORTED; }
+    const int passes = (n_iter + LV - 1) / LV;
+    float* pingpong = (float*)ws;
+    const float* hin = blur;
+    int done = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int n = (n_iter - done) < LV ? (n_iter - done) : LV;
+        // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
+        float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
+        Geo geo;
+        geo.B = B; geo.H = H; geo.W = W; geo.n_iter = n;
+        geo.halo = 4 * ((n + 3) / 4);
+        geo.nb = bands_of(W, geo.halo);
+        const long long total = (long long)B * geo.nb * H;
+        long long grid = total / MIN_ROWS_PER_WG;
+        if (grid < 1) grid = 1;
+        if (grid > num_cus()) grid = num_cus();
+        const bool hd = hin != blur;
+        const bool sp = sparse != nullptr;
+        switch (norm * 2 + (sp ? 1 : 0)) {
+            case 0: launch_pass<0, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 1: launch_pass<0, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 2: launch_pass<1, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 3: launch_pass<1, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 4: launch_pass<2, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            default: launch_pass<2, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+        }
+        if (int e = check_launch("cspn2d_fused_kernel")) return e;
+        hin = dst;
+        done += n;
+    }
+    return 0;
+}
+
 }  // namespace cspn

@@ -46,8 +46,10 @@ def test_argument_errors_are_reported_without_gpu():
     fake = ctypes.c_void_p(4096)
     rc = lib.cspn2d_forward_f32(fake, fake, None, fake, 1, 4, 4, 3, 7, None, 0, None)
     assert rc == -1 and b"norm_type" in lib.cspn_last_error()
-    rc = lib.cspn2d_forward_f32(fake, fake, None, fake, 1, 4, 4, 3, 0, None, 0, None)
+    rc = lib.cspn2d_forward_f32(fake, fake, None, fake, 1, 4, 5, 3, 0, None, 0, None)  # W%4 != 0 -> stepwise
     assert rc == -2 and b"workspace" in lib.cspn_last_error()
+    rc = lib.cspn2d_forward_f32_algo(fake, fake, None, fake, 1, 4, 5, 3, 0, 2, None, 0, None)  # fused refused
+    assert rc == -3 and b"fused" in lib.cspn_last_error()
     rc = lib.cspn2d_forward_f32(fake, fake, None, fake, 1, 4, 4, -1, 0, None, 0, None)
     assert rc == -1
     rc = lib.cspn3d_forward_f32(fake, fake, None, fake, 1, 2, 4, 4, 3, 0, None, 0, None)

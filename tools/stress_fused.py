@@ -1,0 +1,30 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import cspn_amd
+np.set_printoptions(linewidth=220)
+def run(B,H,W,N,sp,reps):
+    gen = torch.Generator(device="cuda").manual_seed(B+H+W)
+    g = torch.randn(B,8,H,W,generator=gen,device="cuda"); h = torch.rand(B,1,H,W,generator=gen,device="cuda")*10
+    s = ((torch.rand(B,1,H,W,generator=gen,device="cuda")<0.01).float()*(h+0.1)) if sp else None
+    ref = cspn_amd.cspn2d_forward(g,h,s,N,"8sum","stepwise"); torch.cuda.synchronize()
+    nbad = 0
+    for r in range(reps):
+        o = cspn_amd.cspn2d_forward(g,h,s,N,"8sum","fused"); torch.cuda.synchronize()
+        d = (o-ref).abs(); d[torch.isnan(d)] = 1e9
+        if float(d.max()) > 1e-3:
+            nbad += 1
+            if nbad <= 3:
+                bad = (d > 1e-3).nonzero().cpu().numpy()
+                print(" rep",r,"bad px",len(bad),"imgs",sorted(set(bad[:,0].tolist()))[:10])
+                ys = bad[:,2]; xs = bad[:,3]
+                print("   rows min/max", ys.min(), ys.max(), "cols min/max", xs.min(), xs.max())
+                b0 = bad[bad[:,0]==bad[0,0]]
+                rows = sorted(set(b0[:,2].tolist())); print("   img",bad[0,0],"rows:", rows[:60])
+                r0 = rows[0]; cols = sorted(b0[b0[:,2]==r0][:,3].tolist()); print("   first bad row",r0,"cols:", cols[:80])
+    print("case",(B,H,W,N,sp),"reps",reps,"bad runs",nbad)
+run(1,26,280,24,True,300)
+run(16,228,304,24,True,100)
+run(8,304,1216,24,False,30)
+run(1,64,64,24,False,300)
