@@ -36,7 +36,7 @@ constexpr int R = 4;         // resident rows (slots) per wave
 constexpr int LV = 24;       // NW*(R-1): iterations fused per pass
 constexpr int BW = 256;      // band width in pixels: 64 lanes x 4 columns
 constexpr int NT = NW * 64;  // threads per workgroup
-constexpr int MIN_ROWS_PER_WG = 128;
+constexpr int MIN_ROWS_PER_WG = 16;  // a workgroup pays ~2*n_iter halo rows + a 24-step drain; more workgroups still win
 
 struct Lds {
     float bnd[2][NW][2][BW];  // [step parity][wave][0: top row (slot 0) | 1: bottom row (slot 3)]
@@ -104,29 +104,25 @@ __device__ __forceinline__ void wg_barrier() {
 #endif
 }
 
+#ifdef CSPN_DBG_TIMING
+__device__ long long g_tim[8 * 8];  // [wave][phase] cycle totals of block 0
+#define TIM_DECL long long tim_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tim_t0 = clock64();
+#define TIM(i) do { const long long t_ = clock64(); tim_[i] += t_ - tim_t0; tim_t0 = t_; } while (0)
+#define TIM_FLUSH() do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) g_tim[wv * 8 + i_] = tim_[i_]; } } while (0)
+#else
+#define TIM_DECL
+#define TIM(i) do { } while (0)
+#define TIM_FLUSH() do { } while (0)
+#endif
+
 // ---- the stream of rows a workgroup processes ------------------------------------------------
 struct Geo {
     int B, H, W, n_iter, nb, halo;  // nb bands per image, horizontal halo (multiple of 4)
 };
-#ifdef CSPN_DBG_CHECK
-__device__ int g_dbg[32];
-__device__ int g_trace[2048 * 8];
-__device__ int g_ntrace;
-#define DBG_CHECK(cond, code, a, b, c, d)                                                  \
-    do {                                                                                   \
-        if (!(cond)) {                                                                     \
-            if (atomicAdd(&g_dbg[0], 1) == 0) {                                            \
-                g_dbg[1] = (code); g_dbg[2] = (a); g_dbg[3] = (b); g_dbg[4] = (c); g_dbg[5] = (d); \
-                g_dbg[6] = blockIdx.x; g_dbg[7] = threadIdx.x;                             \
-            }                                                                              \
-        }                                                                                  \
-    } while (0)
-#else
-#define DBG_CHECK(cond, code, a, b, c, d) do { } while (0)
-#endif
 struct RowInfo {
     int active;   // 0: separator / past-the-end row (stays exactly zero)
-    int b, y, p0; // image, image row, first physical column of the band
+    int y, p0;    // image row, first physical column of the band
+    int img;      // b*H*W: element offset of the image inside a 1-channel tensor
     int outoff;   // element offset of out[b][0][y][p0], or -1 when the row is only halo
     int lo, hi;   // owned columns, band relative
 };
@@ -139,34 +135,42 @@ __device__ __forceinline__ void band_of(const Geo& g, int bi, int& p0, int& lo, 
 struct Cursor {
     int r_next, r_end;  // [r_next, r_end): still unopened part of this workgroup's share of B*nb*H rows
     int in_seg, pending;
-    int b, p0, lo, hi, y0, y1, ye, y;
+    int img, p0, lo, hi, y0, y1, ye, y;
     __device__ __forceinline__ void init(int r0, int r1) {
         r_next = r0; r_end = r1; in_seg = 0; pending = r0 < r1;
-        b = p0 = lo = hi = y0 = y1 = ye = y = 0;
+        img = p0 = lo = hi = y0 = y1 = ye = y = 0;
     }
     __device__ __forceinline__ void open(const Geo& g) {
         const int u = r_next / g.H;
         y0 = r_next - u * g.H;
         y1 = min(g.H, y0 + (r_end - r_next));
         r_next += y1 - y0;
-        b = u / g.nb;
-        band_of(g, u - b * g.nb, p0, lo, hi);
+        const int b = u / g.nb;
+        int plo, phi;
+        band_of(g, u - b * g.nb, p0, plo, phi);
+        lo = plo - p0; hi = phi - p0;
+        img = b * g.H * g.W;
         y = max(0, y0 - g.n_iter);
         ye = min(g.H, y1 + g.n_iter);
         in_seg = 1; pending = 0;
     }
     __device__ __forceinline__ RowInfo next(const Geo& g) {
-        RowInfo r; r.active = 0; r.b = 0; r.y = 0; r.p0 = 0; r.outoff = -1; r.lo = 0; r.hi = 0;
-        if (in_seg && y >= ye) {  // segment exhausted: emit a separator (or idle rows at the very end)
+        RowInfo r;
+        if (__builtin_expect(in_seg && y < ye, 1)) {
+            r.active = 1; r.y = y; r.p0 = p0; r.img = img; r.lo = lo; r.hi = hi;
+            r.outoff = (y >= y0 && y < y1) ? (img + y * g.W + p0) : -1;
+            ++y;
+            return r;
+        }
+        r.active = 0; r.y = 0; r.p0 = 0; r.img = 0; r.outoff = -1; r.lo = 0; r.hi = 0;
+        if (in_seg) {  // segment exhausted: emit a separator (or idle rows at the very end)
             in_seg = 0; pending = r_next < r_end;
             return r;
         }
-        if (!in_seg) {
-            if (!pending) return r;
-            open(g);
-        }
-        r.active = 1; r.b = b; r.y = y; r.p0 = p0; r.lo = lo - p0; r.hi = hi - p0;
-        r.outoff = (y >= y0 && y < y1) ? ((b * g.H + y) * g.W + p0) : -1;
+        if (!pending) return r;
+        open(g);
+        r.active = 1; r.y = y; r.p0 = p0; r.img = img; r.lo = lo; r.hi = hi;
+        r.outoff = (y >= y0 && y < y1) ? (img + y * g.W + p0) : -1;
         ++y;
         return r;
     }
@@ -187,78 +191,98 @@ struct Pend {  // one pixel's raw inputs, loaded one cook event ahead
     float g[8], blur, hin, sp;
 };
 
+// uniform row pointer + unsigned per-lane byte offset -> global_load with scalar base (no 64-bit VALU math)
+__device__ __forceinline__ float ld_row(const float* row, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + byte_off);
+}
+
+// Straight-line, branch-free: every lane of every wave issues all loads from clamped (always valid)
+// addresses so they stay in flight until the next cook event; whatever is outside the image (or belongs
+// to a separator row) is zeroed when the pixel is cooked.
 template <int NORM, bool SPARSE, bool HIN>
 __device__ __forceinline__ void issue_loads(Pend& p, const RowInfo& ri, int x, const Geo& g, const float* __restrict__ gd,
                                             const float* __restrict__ blur, const float* __restrict__ hin,
                                             const float* __restrict__ sparse) {
     const int HW = g.H * g.W;
-    const int xg = ri.p0 + x;  // image column
-    const bool in = ri.active && xg < g.W;
-    const float* gb = gd + (size_t)ri.b * 8 * HW;
+    const int xg = ri.p0 + x;
+    const unsigned oc = 4u * (unsigned)min(xg, g.W - 1);
+    const unsigned ol = 4u * (unsigned)max(min(xg, g.W) - 1, 0);
+    const unsigned orr = 4u * (unsigned)min(xg + 1, g.W - 1);
+    const float* gimg = gd + (size_t)ri.img * 8;
+    const int yu = min(ri.y + 1, g.H - 1), yd = max(ri.y - 1, 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float v = 0.f;
         if (NORM == CSPN_NORM_NONE) {
-            if (in) v = gb[k * HW + ri.y * g.W + xg];
+            p.g[k] = ld_row(gimg + k * HW + ri.y * g.W, oc);
         } else {
-            const int yy = ri.y + dy2(k), xb = x + dx2(k), xx = xg + dx2(k);
-            // the band only sees its own 256 columns: neighbours outside read 0 (halo pixels, never output)
-            if (in && yy >= 0 && yy < g.H && xb >= 0 && xb < BW && xx < g.W) {
-                DBG_CHECK(ri.b >= 0 && ri.b < g.B && yy * g.W + xx >= 0 && yy * g.W + xx < HW, 1, ri.b, yy, xx, k);
-#ifdef CSPN_DBG_CHECK
-                if (ri.b >= 0 && ri.b < g.B && yy * g.W + xx >= 0 && yy * g.W + xx < HW)
-#endif
-                v = gb[k * HW + yy * g.W + xx];
-            }
+            const int yy = dy2(k) > 0 ? yu : (dy2(k) < 0 ? yd : ri.y);
+            p.g[k] = ld_row(gimg + k * HW + yy * g.W, dx2(k) > 0 ? orr : (dx2(k) < 0 ? ol : oc));
         }
-        p.g[k] = v;
     }
-    const int off = (ri.b * g.H + ri.y) * g.W + xg;
-    DBG_CHECK(!in || (off >= 0 && off < g.B * HW && ri.y >= 0 && ri.y < g.H && ri.b >= 0 && ri.b < g.B), 2, ri.b, ri.y, xg, off);
-#ifdef CSPN_DBG_CHECK
-    const bool in_ok = in && off >= 0 && off < g.B * HW && ri.b >= 0 && ri.b < g.B;
-    p.blur = in_ok ? blur[off] : 0.f;
-    p.hin = HIN ? (in_ok ? hin[off] : 0.f) : p.blur;
-    p.sp = (SPARSE && in_ok) ? sparse[off] : 0.f;
-    return;
-#endif
-    p.blur = in ? blur[off] : 0.f;
-    p.hin = HIN ? (in ? hin[off] : 0.f) : p.blur;
-    p.sp = (SPARSE && in) ? sparse[off] : 0.f;
+    const int ro = ri.img + ri.y * g.W;
+    p.blur = ld_row(blur + ro, oc);
+    p.hin = HIN ? ld_row(hin + ro, oc) : 0.f;
+    p.sp = SPARSE ? ld_row(sparse + ro, oc) : 0.f;
 }
 
-template <int NORM, bool SPARSE>
-__device__ __forceinline__ void cook_pixel(const Pend& p, const RowInfo& ri, int q, int x, int W, Lds& lds) {
-    float w[8], S = 0.f, c;
+__device__ __forceinline__ float fast_rcp(float s) {  // ~1 ulp; rcp(0) = inf so 0 * inf = NaN like torch.div's 0/0
+    float r = __builtin_amdgcn_rcpf(s);
+    const float e = fmaf(-s, r, 1.f);
+    return fmaf(e, r, r);
+}
+
+template <int NORM, bool SPARSE, bool HIN>
+__device__ __forceinline__ void cook_pixel(const Pend& p, const RowInfo& ri, int q, int x, const Geo& g, Lds& lds) {
+    const int xg = ri.p0 + x;
+    const bool pv = ri.active && xg < g.W;       // pixel inside the image
+    const bool vl = pv && xg >= 1;               // its left / right neighbour column inside the image
+    const bool vr = pv && xg + 1 < g.W;
+    const bool ru = ri.y + 1 < g.H, rd = ri.y >= 1;  // the row below / above inside the image (wave-uniform)
+    float gv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        w[k] = (NORM == CSPN_NORM_8SUM_ABS) ? fabsf(p.g[k]) : p.g[k];
-        S += fabsf(w[k]);
+        bool ok = pv;
+        if (NORM != CSPN_NORM_NONE) {
+            ok = dx2(k) > 0 ? vr : (dx2(k) < 0 ? vl : pv);
+            ok = ok && (dy2(k) > 0 ? ru : (dy2(k) < 0 ? rd : true));
+        }
+        gv[k] = ok ? p.g[k] : 0.f;
+        if (NORM == CSPN_NORM_8SUM_ABS) gv[k] = fabsf(gv[k]);
     }
-    // separator rows and columns right of the image carry all-zero inputs: make their coefficients
-    // exactly 0 (not 0/0) so they stay zero like the reference's ZeroPad2d border
-    if (!(ri.active && ri.p0 + x < W)) S = 1.f;
-    if (NORM == CSPN_NORM_NONE) {
-        c = 0.f;
-    } else {
-        const float inv = 1.0f / S;  // IEEE division; 0 * inf = NaN reproduces torch.div's 0/0 (cspn.py:138)
-        float sigma = 0.f;
+    const float h0 = pv ? p.blur : 0.f;
+    const float hv = HIN ? (pv ? p.hin : 0.f) : h0;
+    f2 g2[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { w[k] *= inv; sigma += w[k]; }
-        c = (1.f - sigma) * p.blur;  // cspn.py:76
+    for (int k = 0; k < 4; ++k) g2[k] = f2{gv[2 * k], gv[2 * k + 1]};
+    float scale = 1.f, c = 0.f;
+    if (NORM != CSPN_NORM_NONE) {
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) S += fabsf(gv[k]);
+        // separator rows / columns right of the image: all inputs are 0, keep coefficients exactly 0 (not 0/0)
+        S = pv ? S : 1.f;
+        const float inv = fast_rcp(S);
+        const f2 t2 = (g2[0] + g2[1]) + (g2[2] + g2[3]);
+        const float sigma = (t2.x + t2.y) * inv;
+        c = fmaf(-sigma, h0, h0);  // (1 - sigma) * H0, cspn.py:76
+        scale = inv;
     }
-    if (SPARSE) {  // cspn.py:64,81
-        const float m = signf(p.sp), om = 1.f - m;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] *= om;
-        c = om * c + m * p.blur;
+    if (SPARSE) {  // cspn.py:64,81: mask pins to H0; folded into the coefficients
+        const float m = signf(pv ? p.sp : 0.f), om = 1.f - m;
+        scale *= om;
+        c = fmaf(om, c, m * h0);
     }
     const int px = perm4(x);
     const int cb = q & 3;
+    const f2 s2 = f2{scale, scale};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lds.cook[cb][k][px] = w[k];
+    for (int k = 0; k < 4; ++k) {
+        const f2 w2 = (NORM == CSPN_NORM_NONE && !SPARSE) ? g2[k] : g2[k] * s2;
+        lds.cook[cb][2 * k][px] = w2.x;
+        lds.cook[cb][2 * k + 1][px] = w2.y;
+    }
     lds.cook[cb][8][px] = c;
-    lds.h0[q & 7][px] = p.hin;
+    lds.h0[q & 7][px] = hv;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------
@@ -280,17 +304,18 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
     const int last_step = 3 * ((Q - 1) >> 2) + ((Q - 1) & 3) + geo.n_iter;
 
     // ---- register-resident state ----
-    f2 Wt[R][9][2];     // folded coefficients of the 4 resident rows (Wt[j][8] = c')
-    f2 S[2][R][2];      // accumulators, S[step parity][slot][pair]
-    int act[R];                // 0: the slot holds a separator / nothing -> its value is pinned to 0
-    int cnt0 = (LV * 4 - 3 * wv) % LV;  // slot j is at phase (cnt0 - j) mod 24; 0 = injection step
-    int qgen = 0;              // generation: slot j takes stream row 4*(wv + 8*qgen) + j next
+    f2 Wt[R][9][2];  // folded coefficients of the 4 resident rows (Wt[j][8] = c')
+    f2 S[2][R][2];   // accumulators, S[step parity][slot][pair]
+    int act[R] = {0, 0, 0, 0};  // 0: the slot holds a separator / nothing -> its value is pinned to 0
+    int allact = 0;             // all four slots hold real rows (then the event-free fast step is legal)
+    int cnt0 = (LV * 4 - 3 * wv) % LV;               // slot j is at phase (cnt0 - j) mod 24; phase 0 = injection step
+    int rcnt = (cnt0 + 2 * LV - geo.n_iter) % LV;    // slot j retires (level n_iter complete) when (rcnt - j) mod 24 == 0
+    int qgen = 0;    // generation: slot j takes stream row 4*(wv + 8*qgen) + j next
 #pragma unroll
     for (int j = 0; j < R; ++j) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { Wt[j][k][0] = f2{0.f, 0.f}; Wt[j][k][1] = f2{0.f, 0.f}; }
         S[0][j][0] = S[0][j][1] = S[1][j][0] = S[1][j][1] = f2{0.f, 0.f};
-        act[j] = 0;
     }
     for (int i = tid; i < 2 * NW * 2 * BW; i += NT) (&lds.bnd[0][0][0][0])[i] = 0.f;
 
@@ -309,18 +334,18 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
     }
     int ev = 0;
+    TIM_DECL
     auto cook_event = [&]() {
         // consume the pending pixel (loaded one event ago) ...
         if (pq >= 0) {
-            cook_pixel<NORM, SPARSE>(pend, pinfo, pq, cx, geo.W, lds);
-            if (cx == 0) {
-                lds.hdr[pq & 3][0] = pinfo.active; lds.hdr[pq & 3][1] = pinfo.outoff;
-                lds.hdr[pq & 3][2] = pinfo.lo; lds.hdr[pq & 3][3] = pinfo.hi;
-            }
+            cook_pixel<NORM, SPARSE, HIN>(pend, pinfo, pq, cx, geo, lds);
+            if (cx == 0) *reinterpret_cast<int4*>(&lds.hdr[pq & 3][0]) = make_int4(pinfo.active, pinfo.outoff, pinfo.lo, pinfo.hi);
         }
+        TIM(5);
         // ... and issue the loads of the next event's rows
         ++ev;
-        const RowInfo ra = cur.next(geo), rb = cur.next(geo);
+        const RowInfo ra = cur.next(geo);
+        const RowInfo rb = cur.next(geo);
         pinfo = crow ? rb : ra;
         pq = 2 * ev - 1 + crow;
         issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
@@ -329,46 +354,28 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
     wg_barrier();
 
     int tau_cur = 0;
-#ifdef CSPN_DBG_CHECK
-    int dbg_tau = -1;
-#endif
     // ---- per-slot events: zero inactive rows, retire (write level n_iter), inject the next stream row
     auto slot_events = [&](auto JT, f2& v0, f2& v1, f2& n20, f2& n21) -> bool {
         constexpr int j = decltype(JT)::value;
         if (!act[j]) { v0 = f2{0.f, 0.f}; v1 = f2{0.f, 0.f}; }
-        const int cntj = cnt0 >= j ? cnt0 - j : cnt0 + LV - j;
-        // phase 0 = this slot's row completed level 24 and the next stream row enters.  (wave 7, slot 3) has
-        // phi = 24 == 0 (mod 24): its counter is also 0 at step 0, before its first row exists.
-        const bool inj = cntj == 0 && tau_cur >= 3 * wv + j;
-        const int lvl = cntj == 0 ? LV : cntj;
-        if (lvl == geo.n_iter && act[j]) {
-            const int outoffj = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][1]);
-            const int oloj = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][2]);
-            const int ohij = __builtin_amdgcn_readfirstlane(lds.meta[wv][j][3]);
+        if (rcnt == j && act[j]) {  // this row just completed level n_iter: write it
+            const int4 md = *reinterpret_cast<const int4*>(&lds.meta[wv][j][0]);
+            const int outoffj = __builtin_amdgcn_readfirstlane(md.y);
+            const int oloj = __builtin_amdgcn_readfirstlane(md.z);
+            const int ohij = __builtin_amdgcn_readfirstlane(md.w);
             const int xb = 4 * lane;
-            if (outoffj >= 0 && xb >= oloj && xb < ohij) {
-                DBG_CHECK(outoffj + xb >= 0 && outoffj + xb + 3 < geo.B * geo.H * geo.W && oloj >= 0 && ohij <= BW, 3, outoffj, oloj, ohij, (j << 16) | cntj);
-#ifdef CSPN_DBG_CHECK
-                if (outoffj + xb >= 0 && outoffj + xb + 3 < geo.B * geo.H * geo.W)
-#endif
+            if (outoffj >= 0 && xb >= oloj && xb < ohij)
                 *reinterpret_cast<float4*>(out + (size_t)outoffj + xb) = make_float4(v0.x, v1.x, v0.y, v1.y);
-            }
         }
+        // phase 0 = the slot's row completed level 24 and the next stream row enters.  (wave 7, slot 3) has
+        // phi = 24 == 0 (mod 24): its counter is also 0 at step 0, before its first row exists.
+        const bool inj = cnt0 == j && tau_cur >= 3 * wv + j;
         if (inj) {
             const int q = 4 * (wv + NW * qgen) + j;
             const int cb = q & 3;
             const int4 hd = *reinterpret_cast<const int4*>(&lds.hdr[cb][0]);
             *reinterpret_cast<int4*>(&lds.meta[wv][j][0]) = hd;  // kept for this row's retirement (same wave: in order)
             act[j] = __builtin_amdgcn_readfirstlane(hd.x);
-#ifdef CSPN_DBG_CHECK
-            if (blockIdx.x == 0 && lane == 0) {
-                const int t = atomicAdd(&g_ntrace, 1);
-                if (t < 2048) {
-                    g_trace[t * 8 + 0] = dbg_tau; g_trace[t * 8 + 1] = wv; g_trace[t * 8 + 2] = j; g_trace[t * 8 + 3] = q;
-                    g_trace[t * 8 + 4] = hd.x; g_trace[t * 8 + 5] = hd.y; g_trace[t * 8 + 6] = hd.z; g_trace[t * 8 + 7] = hd.w;
-                }
-            }
-#endif
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const float4 t = *reinterpret_cast<const float4*>(&lds.cook[cb][k][4 * lane]);
@@ -393,41 +400,45 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         return inj;
     };
 
-    auto step = [&](auto PT) {
+    // One propagation step of this wave's four rows.  EV = false is the event-free fast path: all
+    // four slots hold real rows and none retires or is replaced this step.
+    auto step = [&](auto PT, auto ET) {
         constexpr int PAR = decltype(PT)::value;
+        constexpr bool EV = decltype(ET)::value;
         f2 (&N1)[R][2] = S[PAR];
         f2 (&N2)[R][2] = S[PAR ^ 1];
+        // boundary rows published by the neighbouring waves in the previous step
         const float4 tq = *reinterpret_cast<const float4*>(&lds.bnd[PAR ^ 1][(wv + NW - 1) & (NW - 1)][1][4 * lane]);
         const float4 bq = *reinterpret_cast<const float4*>(&lds.bnd[PAR ^ 1][(wv + 1) & (NW - 1)][0][4 * lane]);
         Shift s;
-        bool inj;
-        // received rows: above taps for slot 0 (prev block's bottom row), below taps for slot 3 (next block's top row)
-        s = mk_shift(f2{tq.x, tq.y}, f2{tq.z, tq.w});
-        push_above(Wt[0], s, N1[0][0], N1[0][1]);
+        bool inj = false;
+        // received rows: below taps for slot 3 (next block's top row), above taps for slot 0 (prev block's bottom row)
         s = mk_shift(f2{bq.x, bq.y}, f2{bq.z, bq.w});
         push_below(Wt[3], s, N1[3][0], N1[3][1]);
+        s = mk_shift(f2{tq.x, tq.y}, f2{tq.z, tq.w});
+        push_above(Wt[0], s, N1[0][0], N1[0][1]);
         // slot 3 completes
-        inj = slot_events(std::integral_constant<int, 3>{}, N1[3][0], N1[3][1], N2[3][0], N2[3][1]);
+        if (EV) inj = slot_events(std::integral_constant<int, 3>{}, N1[3][0], N1[3][1], N2[3][0], N2[3][1]);
         *reinterpret_cast<float4*>(&lds.bnd[PAR][wv][1][4 * lane]) = make_float4(N1[3][0].x, N1[3][0].y, N1[3][1].x, N1[3][1].y);
         s = mk_shift(N1[3][0], N1[3][1]);
         push_below(Wt[2], s, N1[2][0], N1[2][1]);
         if (!inj) push_self(Wt[3], s, N2[3][0], N2[3][1]);
         // slot 2 completes
-        inj = slot_events(std::integral_constant<int, 2>{}, N1[2][0], N1[2][1], N2[2][0], N2[2][1]);
+        if (EV) inj = slot_events(std::integral_constant<int, 2>{}, N1[2][0], N1[2][1], N2[2][0], N2[2][1]);
         s = mk_shift(N1[2][0], N1[2][1]);
         push_below(Wt[1], s, N1[1][0], N1[1][1]);
         if (!inj) push_self(Wt[2], s, N2[2][0], N2[2][1]);
         N1[3][0] = Wt[3][8][0]; N1[3][1] = Wt[3][8][1];
         push_above(Wt[3], s, N1[3][0], N1[3][1]);
         // slot 1 completes
-        inj = slot_events(std::integral_constant<int, 1>{}, N1[1][0], N1[1][1], N2[1][0], N2[1][1]);
+        if (EV) inj = slot_events(std::integral_constant<int, 1>{}, N1[1][0], N1[1][1], N2[1][0], N2[1][1]);
         s = mk_shift(N1[1][0], N1[1][1]);
         push_below(Wt[0], s, N1[0][0], N1[0][1]);
         if (!inj) push_self(Wt[1], s, N2[1][0], N2[1][1]);
         N1[2][0] = Wt[2][8][0]; N1[2][1] = Wt[2][8][1];
         push_above(Wt[2], s, N1[2][0], N1[2][1]);
         // slot 0 completes
-        inj = slot_events(std::integral_constant<int, 0>{}, N1[0][0], N1[0][1], N2[0][0], N2[0][1]);
+        if (EV) inj = slot_events(std::integral_constant<int, 0>{}, N1[0][0], N1[0][1], N2[0][0], N2[0][1]);
         *reinterpret_cast<float4*>(&lds.bnd[PAR][wv][0][4 * lane]) = make_float4(N1[0][0].x, N1[0][0].y, N1[0][1].x, N1[0][1].y);
         s = mk_shift(N1[0][0], N1[0][1]);
         if (!inj) {
@@ -436,46 +447,38 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         }
         N1[1][0] = Wt[1][8][0]; N1[1][1] = Wt[1][8][1];
         push_above(Wt[1], s, N1[1][0], N1[1][1]);
-        cnt0 = (cnt0 + 1 == LV) ? 0 : cnt0 + 1;
+        if (EV) allact = act[0] & act[1] & act[2] & act[3];
     };
 
     int tau3 = 0;  // tau mod 3
-    for (int tau = 0; tau <= last_step; tau += 2) {
+    auto do_step = [&](auto PT, int tau) {
         tau_cur = tau;
-#ifdef CSPN_DBG_CHECK
-        dbg_tau = tau;
-#endif
-        step(std::integral_constant<int, 0>{});
+        TIM(0);
+        const bool events = (cnt0 < R && tau >= 3 * wv + cnt0) || rcnt < R || !allact;
+        if (events) { step(PT, std::true_type{}); TIM(3); }
+        else { step(PT, std::false_type{}); TIM(2); }
+        cnt0 = (cnt0 + 1 == LV) ? 0 : cnt0 + 1;
+        rcnt = (rcnt + 1 == LV) ? 0 : rcnt + 1;
         if (tau3 != 1) cook_event();
         tau3 = tau3 == 2 ? 0 : tau3 + 1;
+        TIM(1);
         wg_barrier();
+        TIM(4);
+    };
+    for (int tau = 0; tau <= last_step; tau += 2) {
+        do_step(std::integral_constant<int, 0>{}, tau);
         if (tau + 1 > last_step) break;
-        tau_cur = tau + 1;
-#ifdef CSPN_DBG_CHECK
-        dbg_tau = tau + 1;
-#endif
-        step(std::integral_constant<int, 1>{});
-        if (tau3 != 1) cook_event();
-        tau3 = tau3 == 2 ? 0 : tau3 + 1;
-        wg_barrier();
+        do_step(std::integral_constant<int, 1>{}, tau + 1);
     }
+    TIM_FLUSH();
 }
 
-#ifdef CSPN_DBG_CHECK
+#ifdef CSPN_DBG_TIMING
 }  // namespace
 }  // namespace cspn
-extern "C" int cspn_debug_trace(int* dst, int* n) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(n, HIP_SYMBOL(cspn::g_ntrace), sizeof(int));
-    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(cspn::g_trace), sizeof(int) * 2048 * 8);
-    int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(cspn::g_ntrace), &z, sizeof(int));
-    return (int)e;
-}
-extern "C" int cspn_debug_read(int* dst, int reset) {
-    hipDeviceSynchronize();
-    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(cspn::g_dbg), sizeof(int) * 32);
-    if (reset) { int z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(cspn::g_dbg), z, sizeof(z)); }
-    return (int)e;
+extern "C" int cspn_debug_timing(long long* dst) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cspn::g_tim), sizeof(long long) * 64);
 }
 namespace cspn {
 namespace {
