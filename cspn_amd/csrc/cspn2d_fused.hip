@@ -358,44 +358,53 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
     auto slot_events = [&](auto JT, f2& v0, f2& v1, f2& n20, f2& n21) -> bool {
         constexpr int j = decltype(JT)::value;
         if (!act[j]) { v0 = f2{0.f, 0.f}; v1 = f2{0.f, 0.f}; }
-        if (rcnt == j && act[j]) {  // this row just completed level n_iter: write it
-            const int4 md = *reinterpret_cast<const int4*>(&lds.meta[wv][j][0]);
-            const int outoffj = __builtin_amdgcn_readfirstlane(md.y);
-            const int oloj = __builtin_amdgcn_readfirstlane(md.z);
-            const int ohij = __builtin_amdgcn_readfirstlane(md.w);
-            const int xb = 4 * lane;
-            if (outoffj >= 0 && xb >= oloj && xb < ohij)
-                *reinterpret_cast<float4*>(out + (size_t)outoffj + xb) = make_float4(v0.x, v1.x, v0.y, v1.y);
-        }
+        const bool ret = rcnt == j && act[j];
         // phase 0 = the slot's row completed level 24 and the next stream row enters.  (wave 7, slot 3) has
         // phi = 24 == 0 (mod 24): its counter is also 0 at step 0, before its first row exists.
         const bool inj = cnt0 == j && tau_cur >= 3 * wv + j;
-        if (inj) {
+        if (ret | inj) {
+            // every LDS read of this event is issued before the first one is consumed: one round trip, not four
             const int q = 4 * (wv + NW * qgen) + j;
             const int cb = q & 3;
-            const int4 hd = *reinterpret_cast<const int4*>(&lds.hdr[cb][0]);
-            *reinterpret_cast<int4*>(&lds.meta[wv][j][0]) = hd;  // kept for this row's retirement (same wave: in order)
-            act[j] = __builtin_amdgcn_readfirstlane(hd.x);
+            int4 md = make_int4(0, -1, 0, 0), hd = md;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f), ha = h;
+            const f2 o0 = v0, o1 = v1;  // the completed value (written below if the row retires)
+            if (ret) md = *reinterpret_cast<const int4*>(&lds.meta[wv][j][0]);
+            if (inj) {
+                hd = *reinterpret_cast<const int4*>(&lds.hdr[cb][0]);
+                h = *reinterpret_cast<const float4*>(&lds.h0[q & 7][4 * lane]);
+                if (j > 0) ha = *reinterpret_cast<const float4*>(&lds.h0[(q - 1) & 7][4 * lane]);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float4 t = *reinterpret_cast<const float4*>(&lds.cook[cb][k][4 * lane]);
-                Wt[j][k][0] = f2{t.x, t.y};
-                Wt[j][k][1] = f2{t.z, t.w};
+                for (int k = 0; k < 9; ++k) {
+                    const float4 t = *reinterpret_cast<const float4*>(&lds.cook[cb][k][4 * lane]);
+                    Wt[j][k][0] = f2{t.x, t.y};
+                    Wt[j][k][1] = f2{t.z, t.w};
+                }
             }
-            const float4 h = *reinterpret_cast<const float4*>(&lds.h0[q & 7][4 * lane]);
-            v0 = f2{h.x, h.y};
-            v1 = f2{h.z, h.w};
-            // accumulator of level 1: c' + self taps of H0(q) (+ above taps of H0(q-1), same wave)
-            n20 = Wt[j][8][0];
-            n21 = Wt[j][8][1];
-            const Shift s = mk_shift(v0, v1);
-            push_self(Wt[j], s, n20, n21);
-            if (j > 0) {
-                const float4 ha = *reinterpret_cast<const float4*>(&lds.h0[(q - 1) & 7][4 * lane]);
-                const Shift sa = mk_shift(f2{ha.x, ha.y}, f2{ha.z, ha.w});
-                push_above(Wt[j], sa, n20, n21);
+            if (ret) {  // this row just completed level n_iter: write it
+                const int outoffj = __builtin_amdgcn_readfirstlane(md.y);
+                const int oloj = __builtin_amdgcn_readfirstlane(md.z);
+                const int ohij = __builtin_amdgcn_readfirstlane(md.w);
+                const int xb = 4 * lane;
+                if (outoffj >= 0 && xb >= oloj && xb < ohij)
+                    *reinterpret_cast<float4*>(out + (size_t)outoffj + xb) = make_float4(o0.x, o1.x, o0.y, o1.y);
             }
-            if (j == R - 1) ++qgen;
+            if (inj) {
+                *reinterpret_cast<int4*>(&lds.meta[wv][j][0]) = hd;  // kept for this row's retirement (same wave: in order)
+                act[j] = __builtin_amdgcn_readfirstlane(hd.x);
+                v0 = f2{h.x, h.y};
+                v1 = f2{h.z, h.w};
+                // accumulator of level 1: c' + self taps of H0(q) (+ above taps of H0(q-1), same wave)
+                n20 = Wt[j][8][0];
+                n21 = Wt[j][8][1];
+                const Shift s = mk_shift(v0, v1);
+                push_self(Wt[j], s, n20, n21);
+                if (j > 0) {
+                    const Shift sa = mk_shift(f2{ha.x, ha.y}, f2{ha.z, ha.w});
+                    push_above(Wt[j], sa, n20, n21);
+                }
+                if (j == R - 1) ++qgen;
+            }
         }
         return inj;
     };
