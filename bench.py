@@ -98,8 +98,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    shared_gpu = world > ndev  # more ranks than GPUs: only for exercising the launch path on a 1-GPU box
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import cspn_amd
     from cspn_amd import _lib
     lib = cspn_amd.load()
@@ -109,8 +112,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        if not a.no_broadcast:
+        if shared_gpu:  # RCCL refuses two ranks on one device; gloo keeps the control flow identical
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if not a.no_broadcast and not shared_gpu:
             from cspn_amd.dist import broadcast_flat_
             buf = torch.empty(BACKBONE_PARAMS, dtype=torch.float32, device=dev).normal_()
             broadcast_flat_([buf[:1024]])  # communicator warm-up
@@ -160,7 +166,7 @@ def main():
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
 
     if dist is not None:
-        t = torch.tensor([elapsed, dev_ms_avg], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms_avg = float(t[0]), float(t[1])
 
@@ -188,7 +194,8 @@ def main():
             "config": {
                 "workload": "%s, batch %d per GPU" % (desc, B),
                 "B_per_gpu": B, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
-                "algo": algo_name, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                "algo": algo_name, "parallelism": "batch-sharded x%d, no data-path collective" % world
+                                          + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
             },
             "roofline": {
                 "bound": "hbm",
