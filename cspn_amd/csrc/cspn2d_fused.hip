@@ -40,10 +40,11 @@ constexpr int MIN_ROWS_PER_WG = 16;  // a workgroup pays ~2*n_iter halo rows + a
 
 struct Lds {
     float bnd[2][NW][2][BW];  // [step parity][wave][0: top row (slot 0) | 1: bottom row (slot 3)]
-    float cook[4][9][BW];     // folded coefficients of stream row q in cook[q & 3]
-    float h0[8][BW];          // level-0 value of stream row q in h0[q & 7]
-    int hdr[4][4];            // per cooked row: active, out offset (or -1), own lo, own hi (band relative)
+    float cook[8][9][BW];     // folded coefficients of stream row q in cook[q & 7], (c0,c2,c1,c3) per lane
+    float h0[8][BW];          // level-0 value of stream row q in h0[q & 7], same layout
+    int hdr[8][4];            // per cooked row: active, out offset (or -1), own lo, own hi (band relative)
     int meta[NW][R][4];       // the same record for the row currently held by (wave, slot)
+    int rinfo[16][8];         // descriptor of stream row q in rinfo[q & 15] (written by wave 0 only)
 };
 
 // ---- lane-crossing moves (DPP, whole-wave shift by one lane; edge lanes read 0) -------------
@@ -87,9 +88,6 @@ __device__ __forceinline__ void push_self(const f2 (&w)[9][2], const Shift& s, f
     a1 = pkfma(w[4][1], s.p0, a1);
 }
 
-// band column x -> position inside the LDS row: each lane's 4 columns are stored (c0,c2,c1,c3)
-// so one ds_read_b128 yields the two register pairs with no shuffles.
-__device__ __forceinline__ int perm4(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
 
 __device__ __forceinline__ void wg_barrier() {
 #if defined(CSPN_DBG_SYNCTHREADS)
@@ -187,42 +185,43 @@ __device__ __forceinline__ int stream_length(const Geo& g, int r0, int r1) {
 }
 
 // ---- cooking: per pixel normalise + fold (cspn.py:85-144, :76, :81) ---------------------------
-struct Pend {  // one pixel's raw inputs, loaded one cook event ahead
-    float g[8], blur, hin, sp;
+// ---- cooking: a TASK = half a row (128 pixels), 2 adjacent pixels per lane, done by one wave -------------
+// (normalise + fold of cspn.py:85-144, :76, :81).  Per pixel this costs a third of the instructions of a
+// one-pixel-per-thread formulation, and instructions per SIMD are what bounds this kernel.
+struct Pend {  // raw inputs of the lane's two pixels, loaded one step ahead (8-byte loads, 4-byte aligned)
+    f2 g[8], blur, hin, sp;
 };
 
-// uniform row pointer + unsigned per-lane byte offset -> global_load with scalar base (no 64-bit VALU math)
-__device__ __forceinline__ float ld_row(const float* row, unsigned byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + byte_off);
+__device__ __forceinline__ f2 ld_row2(const float* row, unsigned byte_off) {  // scalar row base + per-lane byte offset
+    return *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(row) + byte_off);
 }
 
-// Straight-line, branch-free: every lane of every wave issues all loads from clamped (always valid)
-// addresses so they stay in flight until the next cook event; whatever is outside the image (or belongs
-// to a separator row) is zeroed when the pixel is cooked.
+// Straight-line, branch-free: all loads come from clamped (always valid) addresses so they stay in flight until the
+// next step; whatever is outside the image (or belongs to a separator row) is zeroed when the task is cooked.
+// A +-1 pixel shift stays inside the tensor: the element before a row start / after a row end belongs to the
+// neighbouring row or channel for every plane that is read shifted (channels 2,4,7 shift left, 0,3,5 right).
 template <int NORM, bool SPARSE, bool HIN>
-__device__ __forceinline__ void issue_loads(Pend& p, const RowInfo& ri, int x, const Geo& g, const float* __restrict__ gd,
+__device__ __forceinline__ void issue_loads(Pend& p, const RowInfo& ri, int xb, const Geo& g, const float* __restrict__ gd,
                                             const float* __restrict__ blur, const float* __restrict__ hin,
                                             const float* __restrict__ sparse) {
-    const int HW = g.H * g.W;
-    const int xg = ri.p0 + x;
-    const unsigned oc = 4u * (unsigned)min(xg, g.W - 1);
-    const unsigned ol = 4u * (unsigned)max(min(xg, g.W) - 1, 0);
-    const unsigned orr = 4u * (unsigned)min(xg + 1, g.W - 1);
-    const float* gimg = gd + (size_t)ri.img * 8;
-    const int yu = min(ri.y + 1, g.H - 1), yd = max(ri.y - 1, 0);
+    const unsigned HW4 = 4u * (unsigned)(g.H * g.W), W4 = 4u * (unsigned)g.W;
+    const unsigned oc = 4u * (unsigned)min(ri.p0 + xb, g.W - 2);     // lanes right of the image re-read its last pair
+    const int ro = ri.img + ri.y * g.W;                               // element offset of the row in a 1-channel tensor
+    const float* grow = gd + ((size_t)ri.img * 8 + (size_t)(ri.y * g.W));  // channel 0, this row
+    const unsigned up = (ri.y + 1 < g.H) ? W4 : 0u;                   // row below / above, clamped into the image
+    const unsigned dn = (ri.y >= 1) ? W4 : 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (NORM == CSPN_NORM_NONE) {
-            p.g[k] = ld_row(gimg + k * HW + ri.y * g.W, oc);
+            p.g[k] = ld_row2(grow, oc + (unsigned)k * HW4);
         } else {
-            const int yy = dy2(k) > 0 ? yu : (dy2(k) < 0 ? yd : ri.y);
-            p.g[k] = ld_row(gimg + k * HW + yy * g.W, dx2(k) > 0 ? orr : (dx2(k) < 0 ? ol : oc));
+            const unsigned chan = (unsigned)k * HW4 + (dy2(k) > 0 ? up : 0u) - (dy2(k) < 0 ? dn : 0u);
+            p.g[k] = ld_row2(grow, oc + chan + (unsigned)(4 * dx2(k)));
         }
     }
-    const int ro = ri.img + ri.y * g.W;
-    p.blur = ld_row(blur + ro, oc);
-    p.hin = HIN ? ld_row(hin + ro, oc) : 0.f;
-    p.sp = SPARSE ? ld_row(sparse + ro, oc) : 0.f;
+    p.blur = ld_row2(blur + ro, oc);
+    p.hin = HIN ? ld_row2(hin + ro, oc) : f2{0.f, 0.f};
+    p.sp = SPARSE ? ld_row2(sparse + ro, oc) : f2{0.f, 0.f};
 }
 
 __device__ __forceinline__ float fast_rcp(float s) {  // ~1 ulp; rcp(0) = inf so 0 * inf = NaN like torch.div's 0/0
@@ -231,58 +230,58 @@ __device__ __forceinline__ float fast_rcp(float s) {  // ~1 ulp; rcp(0) = inf so
     return fmaf(e, r, r);
 }
 
-template <int NORM, bool SPARSE, bool HIN>
-__device__ __forceinline__ void cook_pixel(const Pend& p, const RowInfo& ri, int q, int x, const Geo& g, Lds& lds) {
-    const int xg = ri.p0 + x;
-    const bool pv = ri.active && xg < g.W;       // pixel inside the image
-    const bool vl = pv && xg >= 1;               // its left / right neighbour column inside the image
-    const bool vr = pv && xg + 1 < g.W;
-    const bool ru = ri.y + 1 < g.H, rd = ri.y >= 1;  // the row below / above inside the image (wave-uniform)
-    float gv[8];
+// Wave-uniform specialisations: YINT = the rows above and below are inside the image; XFULL = the whole 256-column band
+// is inside the image and the row is a real one (not a separator).
+template <int NORM, bool SPARSE, bool HIN, bool YINT, bool XFULL>
+__device__ __forceinline__ void cook_task(const Pend& p, const RowInfo& ri, int q, int xb, const Geo& g, Lds& lds) {
+    const int x0 = ri.p0 + xb;                             // image column of the lane's first pixel (even)
+    const bool pv = XFULL || (ri.active && x0 < g.W);      // both pixels inside the image (W % 4 == 0)
+    const bool el = x0 == 0;                               // pixel 0 has no left neighbour
+    const bool er = x0 + 2 == g.W;                         // pixel 1 has no right neighbour
+    const bool ru = YINT || ri.y + 1 < g.H, rd = YINT || ri.y >= 1;  // row below / above inside the image
+    f2 gv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        bool ok = pv;
+        f2 t = p.g[k];
         if (NORM != CSPN_NORM_NONE) {
-            ok = dx2(k) > 0 ? vr : (dx2(k) < 0 ? vl : pv);
-            ok = ok && (dy2(k) > 0 ? ru : (dy2(k) < 0 ? rd : true));
+            const bool rok = dy2(k) > 0 ? ru : (dy2(k) < 0 ? rd : true);  // wave-uniform
+            if (!rok) t = f2{0.f, 0.f};
+            if (dx2(k) < 0) t.x = el ? 0.f : t.x;
+            if (dx2(k) > 0) t.y = er ? 0.f : t.y;
         }
-        gv[k] = ok ? p.g[k] : 0.f;
-        if (NORM == CSPN_NORM_8SUM_ABS) gv[k] = fabsf(gv[k]);
+        if (!XFULL && !pv) t = f2{0.f, 0.f};  // whatever the clamped load fetched: never let it in
+        if (NORM == CSPN_NORM_8SUM_ABS) t = f2{fabsf(t.x), fabsf(t.y)};
+        gv[k] = t;
     }
-    const float h0 = pv ? p.blur : 0.f;
-    const float hv = HIN ? (pv ? p.hin : 0.f) : h0;
-    f2 g2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g2[k] = f2{gv[2 * k], gv[2 * k + 1]};
-    float scale = 1.f, c = 0.f;
+    f2 h0 = p.blur, hv = HIN ? p.hin : p.blur;
+    f2 scale = f2{1.f, 1.f}, c = f2{0.f, 0.f};
     if (NORM != CSPN_NORM_NONE) {
-        float S = 0.f;
+        f2 S = f2{0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) S += fabsf(gv[k]);
-        // separator rows / columns right of the image: all inputs are 0, keep coefficients exactly 0 (not 0/0)
-        S = pv ? S : 1.f;
-        const float inv = fast_rcp(S);
-        const f2 t2 = (g2[0] + g2[1]) + (g2[2] + g2[3]);
-        const float sigma = (t2.x + t2.y) * inv;
-        c = fmaf(-sigma, h0, h0);  // (1 - sigma) * H0, cspn.py:76
-        scale = inv;
+        for (int k = 0; k < 8; ++k) S += f2{fabsf(gv[k].x), fabsf(gv[k].y)};
+        const f2 T = ((gv[0] + gv[1]) + (gv[2] + gv[3])) + ((gv[4] + gv[5]) + (gv[6] + gv[7]));
+        scale = f2{fast_rcp(S.x), fast_rcp(S.y)};
+        c = __builtin_elementwise_fma(-(T * scale), h0, h0);  // (1 - sigma) * H0, cspn.py:76
     }
     if (SPARSE) {  // cspn.py:64,81: mask pins to H0; folded into the coefficients
-        const float m = signf(pv ? p.sp : 0.f), om = 1.f - m;
+        const f2 m = f2{signf(p.sp.x), signf(p.sp.y)}, om = f2{1.f, 1.f} - m;
         scale *= om;
-        c = fmaf(om, c, m * h0);
+        c = __builtin_elementwise_fma(om, c, m * h0);
     }
-    const int px = perm4(x);
-    const int cb = q & 3;
-    const f2 s2 = f2{scale, scale};
+    if (!XFULL && !pv) { scale = c = hv = f2{0.f, 0.f}; }  // separator rows / columns right of the image stay exactly zero
+    // LDS layout per owner lane (4 columns): (c0,c2,c1,c3); this lane's pixels are (c0,c1) or (c2,c3) of one group
+    const int pos = (xb & ~3) | ((xb >> 1) & 1);
+    const int cb = q & 7;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f2 w2 = (NORM == CSPN_NORM_NONE && !SPARSE) ? g2[k] : g2[k] * s2;
-        lds.cook[cb][2 * k][px] = w2.x;
-        lds.cook[cb][2 * k + 1][px] = w2.y;
+    for (int k = 0; k < 8; ++k) {
+        const f2 w = (NORM == CSPN_NORM_NONE && !SPARSE) ? gv[k] : gv[k] * scale;
+        lds.cook[cb][k][pos] = w.x;
+        lds.cook[cb][k][pos + 2] = w.y;
     }
-    lds.cook[cb][8][px] = c;
-    lds.h0[q & 7][px] = hv;
+    lds.cook[cb][8][pos] = c.x;
+    lds.cook[cb][8][pos + 2] = c.y;
+    lds.h0[cb][pos] = hv.x;
+    lds.h0[cb][pos + 2] = hv.y;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------
@@ -319,40 +318,70 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
     }
     for (int i = tid; i < 2 * NW * 2 * BW; i += NT) (&lds.bnd[0][0][0][0])[i] = 0.f;
 
-    // ---- cooking pipeline: event e cooks stream rows (2e-1, 2e); waves 0-3 take the first, 4-7 the second
-    const int crow = wv >> 2;  // which of the event's two rows this thread cooks
-    const int cx = tid & 255;  // its band column
+    // ---- cooking pipeline.  Rows enter at 4 per 3 steps, so every third step (tau % 3 == 2) all eight waves cook
+    // one TASK each: group gamma = (tau + 1) / 3 = stream rows 4*gamma-1 .. 4*gamma+2 (they enter at steps 3*gamma,
+    // 3*gamma, 3*gamma+1, 3*gamma+2), wave w takes half (w & 1) of row 4*gamma - 1 + (w >> 1).  Identical work for
+    // every wave (a step is as slow as its busiest wave).  The raw inputs of a task are loaded by its wave one event
+    // (3 steps) earlier; wave 0 alone walks the stream and publishes row descriptors (lds.rinfo) one event before that
+    // (one scalar unit per CU: scalar work is scarce).
     Cursor cur;
     cur.init(r0, r1);
-    Pend pend;
-    RowInfo pinfo;             // row the pending loads belong to
-    int pq;                    // its stream index
-    {   // event 0: rows (-1, 0)
-        RowInfo rb = cur.next(geo);
-        pinfo = rb; pq = crow ? 0 : -1;
-        if (!crow) pinfo.active = 0;
-        issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
-    }
-    int ev = 0;
-    TIM_DECL
-    auto cook_event = [&]() {
-        // consume the pending pixel (loaded one event ago) ...
-        if (pq >= 0) {
-            cook_pixel<NORM, SPARSE, HIN>(pend, pinfo, pq, cx, geo, lds);
-            if (cx == 0) *reinterpret_cast<int4*>(&lds.hdr[pq & 3][0]) = make_int4(pinfo.active, pinfo.outoff, pinfo.lo, pinfo.hi);
+    int qpub = 0;  // next stream row to publish (wave 0)
+    auto publish_upto = [&](int qlast) {
+        if (wv != 0) return;
+        while (qpub <= qlast) {
+            const RowInfo r = cur.next(geo);
+            if (lane == 0) {
+                int* d = &lds.rinfo[qpub & 15][0];
+                *reinterpret_cast<int4*>(d) = make_int4(r.active, r.y, r.p0, r.img);
+                *reinterpret_cast<int4*>(d + 4) = make_int4(r.outoff, r.lo, r.hi, 0);
+            }
+            ++qpub;
         }
-        TIM(5);
-        // ... and issue the loads of the next event's rows
-        ++ev;
-        const RowInfo ra = cur.next(geo);
-        const RowInfo rb = cur.next(geo);
-        pinfo = crow ? rb : ra;
-        pq = 2 * ev - 1 + crow;
-        issue_loads<NORM, SPARSE, HIN>(pend, pinfo, cx, geo, gd, blur, hin, sparse);
     };
-    cook_event();  // cooks row 0, prefetches rows (1, 2)
+    auto fetch_info = [&](int q) -> RowInfo {
+        const int* d = &lds.rinfo[q & 15][0];
+        const int4 a4 = *reinterpret_cast<const int4*>(d);
+        const int4 b4 = *reinterpret_cast<const int4*>(d + 4);
+        RowInfo r;
+        r.active = __builtin_amdgcn_readfirstlane(a4.x);
+        r.y = __builtin_amdgcn_readfirstlane(a4.y);
+        r.p0 = __builtin_amdgcn_readfirstlane(a4.z);
+        r.img = __builtin_amdgcn_readfirstlane(a4.w);
+        r.outoff = __builtin_amdgcn_readfirstlane(b4.x);
+        r.lo = __builtin_amdgcn_readfirstlane(b4.y);
+        r.hi = __builtin_amdgcn_readfirstlane(b4.z);
+        return r;
+    };
+    Pend pend;
+    RowInfo pinfo;  // row of the pending task
+    int pq = -1;    // its stream row (-1: none), inputs in flight, cooked at the next event
+    const int xb = 128 * (wv & 1) + 2 * lane;  // band column of this lane's first pixel in its task
+    auto load_group = [&](int gamma) {
+        pq = 4 * gamma - 1 + (wv >> 1);
+        if (pq < 0) return;
+        pinfo = fetch_info(pq);
+        issue_loads<NORM, SPARSE, HIN>(pend, pinfo, xb, geo, gd, blur, hin, sparse);
+    };
+    auto cook_pending = [&]() {
+        if (pq < 0) return;
+        const bool yint = pinfo.y >= 1 && pinfo.y + 1 < geo.H;
+        const bool xfull = pinfo.active && pinfo.p0 + BW <= geo.W;
+        if (yint && xfull) cook_task<NORM, SPARSE, HIN, true, true>(pend, pinfo, pq, xb, geo, lds);
+        else if (xfull) cook_task<NORM, SPARSE, HIN, false, true>(pend, pinfo, pq, xb, geo, lds);
+        else cook_task<NORM, SPARSE, HIN, false, false>(pend, pinfo, pq, xb, geo, lds);
+        if ((wv & 1) == 0 && lane == 0)
+            *reinterpret_cast<int4*>(&lds.hdr[pq & 7][0]) = make_int4(pinfo.active, pinfo.outoff, pinfo.lo, pinfo.hi);
+    };
+    // prologue: descriptors of groups 0..2, group 0 cooked, group 1 requested
+    publish_upto(10);
+    wg_barrier();
+    load_group(0);
+    cook_pending();
+    load_group(1);
     wg_barrier();
 
+    int tau3 = 0;  // tau mod 3
     int tau_cur = 0;
     // ---- per-slot events: zero inactive rows, retire (write level n_iter), inject the next stream row
     auto slot_events = [&](auto JT, f2& v0, f2& v1, f2& n20, f2& n21) -> bool {
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         if (ret | inj) {
             // every LDS read of this event is issued before the first one is consumed: one round trip, not four
             const int q = 4 * (wv + NW * qgen) + j;
-            const int cb = q & 3;
+            const int cb = q & 7;
             int4 md = make_int4(0, -1, 0, 0), hd = md;
             float4 h = make_float4(0.f, 0.f, 0.f, 0.f), ha = h;
             const f2 o0 = v0, o1 = v1;  // the completed value (written below if the row retires)
@@ -459,7 +488,6 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         if (EV) allact = act[0] & act[1] & act[2] & act[3];
     };
 
-    int tau3 = 0;  // tau mod 3
     auto do_step = [&](auto PT, int tau) {
         tau_cur = tau;
         TIM(0);
@@ -468,7 +496,12 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_fused_kernel(const float* __rest
         else { step(PT, std::false_type{}); TIM(2); }
         cnt0 = (cnt0 + 1 == LV) ? 0 : cnt0 + 1;
         rcnt = (rcnt + 1 == LV) ? 0 : rcnt + 1;
-        if (tau3 != 1) cook_event();
+        if (tau3 == 2) {                  // the group entering from the next step on
+            const int gamma = (tau + 1) / 3;
+            cook_pending();               // its inputs were requested one event (3 steps) ago
+            load_group(gamma + 1);        // request the next group's
+            publish_upto(4 * gamma + 10); // descriptors up to group gamma + 2 (ring of 16)
+        }
         tau3 = tau3 == 2 ? 0 : tau3 + 1;
         TIM(1);
         wg_barrier();
