@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=64)
-    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-broadcast", action="store_true")
@@ -131,7 +131,7 @@ def main():
     B = a.batch_per_gpu
     g, h, s = synth(B, H, W, scale, sparse, dev, 1000 + rank)
     algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
-    algo_name = {1: "stepwise", 2: "fused"}[algo_id]
+    algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
     norm = _lib.NORM_TYPES[a.norm_type]
     ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -199,7 +199,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cspn2d_fused_kernel (one launch per forward)" if algo_name == "fused"
+                "kernel": ("cspn2d_tsw_kernel (gfx950 assembly main loop; one launch per forward + the row-descriptor "
+                           "planning kernel, both inside the timed region)") if algo_name == "fused" and W >= 256 and n_iter == 24
+                          else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
                           else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

@@ -562,22 +562,39 @@ bool fused2d_supported(int B, int H, int W, int n_iter) {
     return B > 0 && H > 0 && W > 0 && n_iter > 0 && (W % 4) == 0;
 }
 
-size_t fused2d_workspace(int B, int H, int W, int n_iter) {
+static size_t ping_bytes(int B, int H, int W, int n_iter) {
     // one ping buffer for n_iter > 24 (passes alternate between it and `out`)
-    return n_iter > LV ? (size_t)B * H * W * sizeof(float) : 0;
+    return n_iter > LV ? (((size_t)B * H * W * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+
+size_t fused2d_workspace(int B, int H, int W, int n_iter) {
+    // + the row-descriptor table of the assembly passes (cspn2d_tsw.hip), used by every pass of exactly 24 iterations
+    const size_t plan = (n_iter >= LV && tsw2d_supported(B, H, W)) ? tsw2d_plan_bytes(B, H, W) : 0;
+    return ping_bytes(B, H, W, n_iter) + plan;
 }
 
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
-                    int n_iter, int norm, void* ws, hipStream_t st) {
+                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm) {
     if (((uintptr_t)out & 15u) != 0) { set_error("fused kernel needs a 16-byte aligned output"); return CSPN_E_UNSUPPORTED; }
     const int passes = (n_iter + LV - 1) / LV;
     float* pingpong = (float*)ws;
+    void* plan_ws = (char*)ws + ping_bytes(B, H, W, n_iter);
+    const bool asm_ok = use_asm && n_iter >= LV && tsw2d_supported(B, H, W);
+    if (asm_ok) {
+        if (int e = tsw2d_build_plan(B, H, W, plan_ws, st)) return e;
+    }
     const float* hin = blur;
     int done = 0;
     for (int p = 0; p < passes; ++p) {
         const int n = (n_iter - done) < LV ? (n_iter - done) : LV;
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
+        if (asm_ok && n == LV) {
+            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, plan_ws, st)) return e;
+            hin = dst;
+            done += n;
+            continue;
+        }
         Geo geo;
         geo.B = B; geo.H = H; geo.W = W; geo.n_iter = n;
         geo.halo = 4 * ((n + 3) / 4);

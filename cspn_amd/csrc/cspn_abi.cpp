@@ -68,13 +68,14 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
     if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     if (algo == CSPN_ALGO_AUTO) algo = cspn2d_auto_algo(B, H, W, n_iter);
-    if (algo != CSPN_ALGO_STEPWISE && algo != CSPN_ALGO_FUSED) { set_error("unknown algo %d", algo); return CSPN_E_BADARG; }
-    if (algo == CSPN_ALGO_FUSED && !fused2d_supported(B, H, W, n_iter)) {
+    if (algo != CSPN_ALGO_STEPWISE && algo != CSPN_ALGO_FUSED && algo != CSPN_ALGO_FUSED_CXX) { set_error("unknown algo %d", algo); return CSPN_E_BADARG; }
+    const bool fused = algo == CSPN_ALGO_FUSED || algo == CSPN_ALGO_FUSED_CXX;
+    if (fused && !fused2d_supported(B, H, W, n_iter)) {
         set_error("fused kernel does not support B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter);
         return CSPN_E_UNSUPPORTED;
     }
     size_t need = n_iter == 0 ? 0
-                  : (algo == CSPN_ALGO_FUSED ? fused2d_workspace(B, H, W, n_iter)
+                  : (fused ? fused2d_workspace(B, H, W, n_iter)
                                              : stepwise2d_workspace(B, H, W, n_iter));
     if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, need)) return e;
     if (n_iter == 0) {  // reference cspn.py:61,66,83: the loop body never runs
@@ -82,7 +83,7 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
         if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
         return 0;
     }
-    if (algo == CSPN_ALGO_FUSED) return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
+    if (fused) return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st, algo == CSPN_ALGO_FUSED);
     return stepwise2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
 }
 

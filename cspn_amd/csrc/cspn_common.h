@@ -36,6 +36,13 @@ int stepwise3d_forward(const float* g, const float* feat, const float* sparse, f
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
-                    int n_iter, int norm, void* ws, hipStream_t st);
+                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true);
+
+// ---- the same ring with the main loop in gfx950 assembly (cspn2d_tsw.hip); one pass = exactly 24 iterations ----
+bool tsw2d_supported(int B, int H, int W);
+size_t tsw2d_plan_bytes(int B, int H, int W);
+int tsw2d_build_plan(int B, int H, int W, void* plan_ws, hipStream_t st);
+int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
+               int W, int norm, const void* plan_ws, hipStream_t st);
 
 }  // namespace cspn

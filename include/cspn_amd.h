@@ -40,8 +40,10 @@ typedef void* cspn_stream_t;
  * normalized in the channel dimension" by the caller, cspn_paddle/demo.py:47-49). */
 enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2 };
 
-/* algo: AUTO picks the fused single-launch kernel whenever the shape allows it. */
-enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2 };
+/* algo: AUTO picks the fused single-launch kernel whenever the shape allows it.  FUSED runs every pass of exactly 24
+ * iterations through the assembly main loop when the image is at least 256 columns wide; FUSED_CXX forces the
+ * compiler-generated version of the same kernel (A/B tests). */
+enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2, CSPN_ALGO_FUSED_CXX = 3 };
 
 enum {
     CSPN_E_BADARG = -1,   /* null pointer, non-positive size, unknown enum      */

@@ -20,6 +20,7 @@ def _algos(B, H, W, N):
     algos = ["stepwise"]
     if N > 0 and lib.cspn2d_auto_algo(B, H, W, N) == _lib.ALGOS["fused"]:
         algos.append("fused")
+        algos.append("fused_cxx")
     return algos
 
 
@@ -215,3 +216,60 @@ def test_paddle_style_affinity_propagate():
     g2 = g2 / g2.sum(1, keepdim=True)
     o2 = cspn_amd.affinity_propagate(x2.to(DEV), g2.to(DEV), n_iter=4)
     assert rel_err(o2.cpu().numpy(), cspn2d_oracle(g2, x2, None, 4, "none")) <= RTOL
+
+
+# ---- shapes that take the assembly main loop (cspn2d_tsw.hip: W >= 256, passes of exactly 24 iterations) ----------------
+TSW_SHAPES = [
+    (2, 40, 256, 24, "8sum", True),        # one band, both band-edge flags on the same band
+    (1, 70, 512, 24, "8sum", False),       # two bands, the last one shifted to the image edge
+    (3, 33, 304, 24, "8sum_abs", True),    # NYU width: bands at 0 and 48; several images per workgroup share
+    (1, 3, 260, 24, "8sum", True),         # fewer rows than iterations
+    (1, 1, 256, 24, "8sum", False),        # single row: both vertical neighbours missing
+    (2, 50, 300, 48, "8sum", True),        # two assembly passes chained through the ping buffer
+    (1, 64, 516, 30, "8sum_abs", True),    # 24 in assembly + 6 in the compiler-generated kernel
+    (1, 45, 1216, 24, "none", True),       # KITTI width, centre-sited pre-normalised gates
+    (6, 304, 1216, 24, "8sum", True),      # full-size images, every workgroup on the device busy
+]
+
+
+@pytest.mark.parametrize("B,H,W,N,norm,sp", TSW_SHAPES)
+def test_asm_loop_parity_vs_oracle(B, H, W, N, norm, sp):
+    g, h, s = make_inputs(B, H, W, seed=7 * B + H + W + N, sparse=sp, neg=sp, depth_scale=80.0)
+    if norm == "none":
+        g = g.abs() / (g.abs().sum(1, keepdim=True) + 0.25)
+    if H > 20:
+        g[0, :, 9:12, 100:108] = 0.0  # 0/0 -> NaN patch must spread exactly like the reference's (cspn.py:138)
+    ref = cspn2d_oracle(g, h, s, N, norm)
+    outs = {a: _run(g, h, s, N, norm, a) for a in ("fused", "fused_cxx")}
+    for a, o in outs.items():
+        assert rel_err(o, ref) <= RTOL, a
+
+
+def test_asm_plan_table_matches_python_planner():
+    """the descriptor table built on the device == tools/tswgen/plan.py (which the CPU emulator tests run on)"""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.tswgen.plan import build_plan
+    lib = cspn_amd.load()
+    for B, H, W in ((3, 33, 304), (2, 100, 1216), (1, 7, 256)):
+        n_wg, stride = ctypes.c_int(), ctypes.c_int()
+        lib.cspn_debug_tsw_plan_geo(B, H, W, ctypes.byref(n_wg), ctypes.byref(stride))
+        g, h, s = make_inputs(B, H, W, seed=1, sparse=False)
+        gd, hd = g.to(DEV), h.to(DEV)
+        out = torch.empty_like(hd)
+        ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, 24)
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=DEV)
+        rc = lib.cspn2d_forward_f32_algo(gd.data_ptr(), hd.data_ptr(), None, out.data_ptr(), B, H, W, 24, 0,
+                                         _lib.ALGOS["fused"], ws.data_ptr(), ws_bytes, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        hdr_ref, tab_ref = build_plan(B, H, W, 24, n_wg.value)
+        assert tab_ref.shape[1] == stride.value
+        raw = ws.cpu().numpy()
+        hdr_bytes = (n_wg.value * 16 + 255) // 256 * 256
+        hdr = raw[:n_wg.value * 16].view(np.int32).reshape(-1, 4)
+        tab = raw[hdr_bytes:hdr_bytes + tab_ref.nbytes].view(np.uint32).reshape(tab_ref.shape)
+        assert np.array_equal(hdr[:, :2], hdr_ref[:, :2])
+        assert np.array_equal(tab, tab_ref)

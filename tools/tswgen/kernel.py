@@ -1,0 +1,532 @@
+"""tools/tswgen/kernel.py -- generator of the gfx950 main loop of the fused CSPN kernel ("time-skewed wave ring").
+
+Same algorithm as the C++ kernel in cspn_amd/csrc/cspn2d_fused.hip (executable spec: tools/tsw_model.py), but every
+register is assigned by hand and the 24 phases of a wave's ring counter are unrolled, so that
+  * the event-free step is exactly 64 v_pk_fma_f32 + 24 moves + 4 LDS ops,
+  * retire / inject code exists only in the 4 phases that need it, specialised per slot,
+  * cooking (normalise + fold, cspn.py:85-144,:76,:81) exists only in the 8 phases with counter % 3 == 2,
+  * row descriptors come from a table built by a tiny planning kernel and are fetched with scalar loads.
+The C++ side (cspn2d_tsw.hip) provides kernel arguments in fixed SGPRs and the LDS allocation.
+
+Register / LDS maps are module constants; `build(cfg)` returns an isa.Prog.
+cfg: norm (0 '8sum', 1 '8sum_abs', 2 'none'), sparse (bool), hin (bool: level-0 values come from a previous pass),
+n_iter (only 24 for now).
+"""
+from .isa import Prog, V, S, EXEC, schedule, check_hazards
+
+NW, NSLOT, LV = 8, 4, 24
+PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
+DESC_BYTES = 32
+LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 10240
+LDS_BYTES = LDS_RING + 8 * RING_SLOT
+DY = [1, 1, 1, 0, 0, -1, -1, -1]
+DX = [1, 0, -1, 1, -1, 1, 0, -1]
+
+# flags in descriptor dword 3
+F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED = 0, 1, 2, 3, 4, 5
+
+# ---- VGPR map ----
+V_LANE, V_COL4, V_L16 = V(0), V(1), V(2)
+V_WR, V_RT, V_RB = [V(3), V(4)], [V(5), V(6)], [V(7), V(8)]
+V_RINGR = V(9)
+V_RINGW = [V(10), V(11)]
+V_OFFK = [V(12 + k) for k in range(8)]
+V_OFF1 = V(20)
+V_TMP = V(21)
+TQ, BQ, TA, TB, HN, HA, OUTQ = V(24, 4), V(28, 4), V(32, 4), V(36, 4), V(40, 4), V(44, 4), V(48, 4)
+CK = V(24, 28)  # cooking temporaries alias the step temporaries
+PEND_G = [V(52 + 2 * k, 2) for k in range(8)]
+PEND_BLUR, PEND_HIN, PEND_SP = V(68, 2), V(70, 2), V(72, 2)
+ACC_BASE, WT_BASE = 76, 108
+
+
+def ACC(p, j):
+    return V(ACC_BASE + (p * 4 + j) * 4, 4)
+
+
+def WT(j, k):
+    return V(WT_BASE + (j * 9 + k) * 4, 4)
+
+
+# ---- SGPR map ----
+S_GD, S_BLUR, S_HIN, S_SP, S_OUT, S_PLAN = S(16, 2), S(18, 2), S(20, 2), S(22, 2), S(24, 2), S(26, 2)
+S_W4, S_HW4, S_LAST, S_WV = S(28), S(29), S(30), S(31)
+S_LDSB = S(15)  # LDS base address of the kernel's __shared__ block
+S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(32), S(33), S(34), S(35), S(36)
+S_EL, S_ER = S(38, 2), S(40, 2)
+EN_F = [S(44), S(45)]           # new row's flags, per event-slot parity
+EO = [S(48, 4), S(52, 4)]       # retiring row's descriptor dwords 2..5 (boff, flags, -, lohi)
+CD = [S(60, 8), S(84, 8)]       # cooking descriptors (double buffered)
+T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
+S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
+
+
+class Gen(object):
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.p = Prog()
+        self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
+        assert cfg.get("n_iter", 24) == 24
+
+    # ---------------------------------------------------------------------------------- small helpers
+    def e(self, op, dst=(), src=(), **m):
+        return self.p.emit(op, dst, src, **m)
+
+    def fma(self, d, a, b, c, **m):
+        self.e("v_pk_fma_f32", d, [a, b, c], **m)
+
+    def mov(self, d, s):
+        self.e("v_mov_b32", d, s)
+
+    def shift(self, q, t):
+        """q = (c0,c2,c1,c3); t <- xl=(c3 of lane-1, c1), xr=(c2, c0 of lane+1)"""
+        self.e("v_mov_b32", t[0], q[3], dpp="wave_shr:1")
+        self.e("v_mov_b32", t[3], q[0], dpp="wave_shl:1")
+        self.mov(t[1], q[2])
+        self.mov(t[2], q[1])
+
+    def push3(self, kr, km, kl, j, q, t, acc, init=None):
+        p0, p1, xl, xr = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2), t.sub(2, 2)
+        a0, a1 = acc.sub(0, 2), acc.sub(2, 2)
+        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (a0, a1)
+        self.fma(a0, WT(j, kr).sub(0, 2), p1, c0)
+        self.fma(a1, WT(j, kr).sub(2, 2), xr, c1)
+        self.fma(a0, WT(j, km).sub(0, 2), p0, a0)
+        self.fma(a1, WT(j, km).sub(2, 2), p1, a1)
+        self.fma(a0, WT(j, kl).sub(0, 2), xl, a0)
+        self.fma(a1, WT(j, kl).sub(2, 2), p0, a1)
+
+    def push_below(self, j, q, t, acc, init=None):
+        self.push3(0, 1, 2, j, q, t, acc, init)
+
+    def push_above(self, j, q, t, acc, init=None):
+        self.push3(5, 6, 7, j, q, t, acc, init)
+
+    def push_self(self, j, q, t, acc, init=None):
+        p0, p1, xl, xr = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2), t.sub(2, 2)
+        a0, a1 = acc.sub(0, 2), acc.sub(2, 2)
+        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (a0, a1)
+        self.fma(a0, WT(j, 3).sub(0, 2), p1, c0)
+        self.fma(a1, WT(j, 3).sub(2, 2), xr, c1)
+        self.fma(a0, WT(j, 4).sub(0, 2), xl, a0)
+        self.fma(a1, WT(j, 4).sub(2, 2), p0, a1)
+
+    def zero_quad(self, q):
+        for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
+            self.mov(q[k], 0)
+
+    def desc_offset(self, dst, qreg, add):
+        """dst <- byte offset of descriptor (qreg + add) in the plan table"""
+        self.e("s_add_i32", dst, [qreg, add + PADF])
+        self.e("s_lshl_b32", dst, [dst, 5])
+
+    # ---------------------------------------------------------------------------------- events
+    def prefetch_event(self, ev):
+        """scalar loads for the event of slot ev (issued one step ahead)"""
+        st = ev & 1
+        self.desc_offset(T[0], S_QB, ev)
+        self.e("s_add_i32", T[1], [T[0], 12])
+        self.e("s_load_dword", EN_F[st], [S_PLAN, T[1]])
+        self.e("s_add_i32", T[1], [T[0], 8 - 32 * DESC_BYTES])
+        self.e("s_load_dwordx4", EO[st], [S_PLAN, T[1]])
+
+    def retire(self, j, vq):
+        st = j & 1
+        eo = EO[st]
+        lab = self.p.newlabel("noret")
+        self.e("s_bitcmp1_b32", (), [S_ACT, j])
+        self.e("s_cbranch_scc0", (), [lab])
+        self.e("s_bitcmp1_b32", (), [eo[1], F_OWNED])
+        self.e("s_cbranch_scc0", (), [lab])
+        self.e("s_and_b32", T[2], [eo[3], 0xffff])
+        self.e("s_lshr_b32", T[3], [eo[3], 16])
+        self.e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
+        self.e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
+        self.e("s_and_b64", S(T[4].i, 2), [S(T[4].i, 2), S(T[6].i, 2)])
+        self.mov(OUTQ[0], vq[0])
+        self.mov(OUTQ[1], vq[2])
+        self.mov(OUTQ[2], vq[1])
+        self.mov(OUTQ[3], vq[3])
+        self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
+        self.e("s_addc_u32", T[9], [S_OUT[1], 0])
+        self.e("s_and_saveexec_b64", S(T[6].i, 2), [S(T[4].i, 2)])
+        self.e("global_store_dwordx4", (), [V_L16, OUTQ, S(T[8].i, 2)])
+        self.e("s_mov_b64", EXEC, [S(T[6].i, 2)])
+        self.p.label(lab)
+
+    def inject(self, j, vq):
+        st = j & 1
+        for k in range(9):
+            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 16)
+        for k in (0, 3, 2, 1):
+            self.mov(vq[k], HN[k])
+        self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
+        self.e("s_bitcmp1_b32", (), [EN_F[st], F_ACTIVE])
+        self.e("s_cselect_b32", T[2], [1 << j, 0])
+        self.e("s_or_b32", S_ACT, [S_ACT, T[2]])
+        if j == 3:
+            self.e("s_add_i32", S_QB, [S_QB, 32])
+
+    def act_check(self, j, vq):
+        lab = self.p.newlabel("act")
+        self.e("s_bitcmp1_b32", (), [S_ACT, j])
+        self.e("s_cbranch_scc1", (), [lab])
+        self.zero_quad(vq)
+        self.p.label(lab)
+
+    # ---------------------------------------------------------------------------------- one phase of the ring counter
+    def step(self, c):
+        p = c & 1
+        N1 = [ACC(p, j) for j in range(4)]
+        N2 = [ACC(p ^ 1, j) for j in range(4)]
+        ev = c if c < 4 else None
+        nxt_ev = (c + 1) % LV if (c + 1) % LV < 4 else None
+        self.p.label(".LS%d_%%=" % c)
+        if ev is not None:
+            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 16)
+            if ev > 0:
+                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 16)
+        self.e("ds_read_b128", BQ, [V_RB[p]])
+        self.e("ds_read_b128", TQ, [V_RT[p]])
+        self.p.waitcnt(lgkm=0)
+        # scalar prefetches whose latency hides behind this step
+        if nxt_ev is not None:
+            self.prefetch_event(nxt_ev)
+        if c % 3 == 2:
+            g = ((c + 1) // 3) & 1
+            self.e("s_add_i32", S_PQ, [S_PQ, 4])
+            self.desc_offset(T[0], S_PQ, 0)
+            self.e("s_load_dwordx8", CD[g], [S_PLAN, T[0]])
+        # received boundary rows
+        self.shift(BQ, TA)
+        self.push_below(3, BQ, TA, N1[3])
+        self.shift(TQ, TB)
+        self.push_above(0, TQ, TB, N1[0])
+        shifts = [TB, TA, TB, TA]  # temp quad for slot j's value: slot 3 -> TA ... alternate
+        for j in (3, 2, 1, 0):
+            vq = N1[j]
+            tq = shifts[j]
+            if ev == j:
+                self.retire(j, vq)
+                self.inject(j, vq)
+            else:
+                self.act_check(j, vq)
+            if j == 3:
+                self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024)
+            if j == 0:
+                self.e("ds_write_b128", (), [V_WR[p], vq], offset=0)
+            self.shift(vq, tq)
+            if j > 0:
+                self.push_below(j - 1, vq, tq, N1[j - 1])
+            if ev == j:
+                self.p.waitcnt(lgkm=0)  # the new coefficients
+                self.push_self(j, vq, tq, N2[j], init=WT(j, 8))
+                if j > 0:
+                    self.shift(HA, OUTQ)
+                    self.push_above(j, HA, OUTQ, N2[j])
+            elif j > 0:
+                self.push_self(j, vq, tq, N2[j])
+            else:
+                self.push_self(0, vq, tq, N2[0], init=WT(0, 8))
+            if j < 3:
+                self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
+        if c % 3 == 2:
+            self.cook_event(((c + 1) // 3) & 1)
+        self.e("s_add_i32", S_TAU, [S_TAU, 1])
+        self.p.waitcnt(lgkm=0)
+        self.e("s_barrier")
+        self.e("s_cmp_gt_u32", (), [S_TAU, S_LAST])
+        self.e("s_cbranch_scc1", (), [".Lexit_%="])
+        if c == LV - 1:
+            self.e("s_branch", (), [".LS0_%="])
+
+    # ---------------------------------------------------------------------------------- cooking
+    def cook_pending(self, ringw):
+        """normalise + fold the pending task (inputs in PEND_*, flags in S_PFLAGS) into the ring slot addressed by ringw"""
+        g = PEND_G
+        norm = self.norm
+        l_inact, l_done = self.p.newlabel("cinact"), self.p.newlabel("cdone")
+        self.p.waitcnt(vm=0)
+        self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_ACTIVE])
+        self.e("s_cbranch_scc0", (), [l_inact])
+        if norm != 2:
+            for flag, chans in ((F_UP, (0, 1, 2)), (F_DN, (5, 6, 7))):
+                lab = self.p.newlabel("edge")
+                self.e("s_bitcmp1_b32", (), [S_PFLAGS, flag])
+                self.e("s_cbranch_scc1", (), [lab])
+                for k in chans:
+                    self.mov(g[k][0], 0)
+                    self.mov(g[k][1], 0)
+                self.p.label(lab)
+            lab = self.p.newlabel("noedge")
+            self.e("s_and_b32", T[0], [S_PFLAGS, (1 << F_FIRST) | (1 << F_LAST)])
+            self.e("s_cbranch_scc0", (), [lab])
+            for k in range(8):
+                if DX[k] < 0:
+                    self.e("v_cndmask_b32", g[k][0], [g[k][0], 0, S_EL])
+                if DX[k] > 0:
+                    self.e("v_cndmask_b32", g[k][1], [g[k][1], 0, S_ER])
+            self.p.label(lab)
+        # temporaries
+        sx, sy = CK[0], CK[1]
+        tt, scale, cc, t2 = CK.sub(2, 2), CK.sub(4, 2), CK.sub(6, 2), CK.sub(8, 2)
+        ex, ey = CK[10], CK[11]
+        mm, om = CK.sub(12, 2), CK.sub(14, 2)
+        h0 = PEND_BLUR
+        if norm == 1:
+            for k in range(8):
+                self.e("v_and_b32", g[k][0], [0x7fffffff, g[k][0]])
+                self.e("v_and_b32", g[k][1], [0x7fffffff, g[k][1]])
+        if norm != 2:
+            self.e("v_add_f32", sx, [g[0][0].abs(), g[1][0].abs()])
+            self.e("v_add_f32", sy, [g[0][1].abs(), g[1][1].abs()])
+            for k in range(2, 8):
+                self.e("v_add_f32", sx, [sx, g[k][0].abs()])
+                self.e("v_add_f32", sy, [sy, g[k][1].abs()])
+            if norm == 0:
+                self.e("v_pk_add_f32", tt, [g[0], g[1]])
+                for k in range(2, 8):
+                    self.e("v_pk_add_f32", tt, [tt, g[k]])
+            self.e("v_rcp_f32", scale[0], [sx])
+            self.e("v_rcp_f32", scale[1], [sy])
+            self.e("v_fma_f32", ex, [-sx, scale[0], 1.0])
+            self.e("v_fma_f32", ey, [-sy, scale[1], 1.0])
+            self.e("v_fma_f32", scale[0], [ex, scale[0], scale[0]])
+            self.e("v_fma_f32", scale[1], [ey, scale[1], scale[1]])
+            if norm == 0:
+                self.e("v_pk_mul_f32", t2, [tt, scale])
+            else:
+                self.mov(tt[0], sx)
+                self.mov(tt[1], sy)
+                self.e("v_pk_mul_f32", t2, [tt, scale])
+            self.fma(cc, t2, h0, h0, neg_lo=[1, 0, 0], neg_hi=[1, 0, 0])  # (1 - sigma) * H0
+        else:
+            self.mov(cc[0], 0)
+            self.mov(cc[1], 0)
+        if self.sparse:
+            # m = sign(sparse) (NaN / 0 pass through), cspn.py:64,81
+            for i in (0, 1):
+                self.mov(mm[i], PEND_SP[i])
+                self.e("v_cmp_gt_f32", S(T[4].i, 2), [PEND_SP[i], 0])
+                self.e("v_cndmask_b32", mm[i], [mm[i], 1.0, S(T[4].i, 2)])
+                self.e("v_cmp_lt_f32", S(T[6].i, 2), [PEND_SP[i], 0])
+                self.e("v_cndmask_b32", mm[i], [mm[i], -1.0, S(T[6].i, 2)])
+                self.e("v_sub_f32", om[i], [1.0, mm[i]])
+            if norm != 2:
+                self.e("v_pk_mul_f32", scale, [scale, om])
+            else:
+                self.mov(scale[0], om[0])
+                self.mov(scale[1], om[1])
+            self.e("v_pk_mul_f32", t2, [mm, h0])
+            self.fma(cc, om, cc, t2)
+        for k in range(8):
+            if norm != 2 or self.sparse:
+                self.e("v_pk_mul_f32", g[k], [g[k], scale])
+            self.e("ds_write2_b32", (), [ringw, g[k][0], g[k][1]], offset0=4 * k, offset1=4 * k + 2)
+        self.e("ds_write2_b32", (), [ringw, cc[0], cc[1]], offset0=32, offset1=34)
+        hv = PEND_HIN if self.hin else PEND_BLUR
+        self.e("ds_write2_b32", (), [ringw, hv[0], hv[1]], offset0=36, offset1=38)
+        self.e("s_branch", (), [l_done])
+        self.p.label(l_inact)
+        self.mov(CK[0], 0)
+        for k in range(10):
+            self.e("ds_write2_b32", (), [ringw, CK[0], CK[0]], offset0=4 * k, offset1=4 * k + 2)
+        self.p.label(l_done)
+
+    def issue_task(self, cd):
+        """request the inputs of the task described by descriptor registers cd; it becomes the pending task"""
+        lab = self.p.newlabel("noload")
+        self.e("s_mov_b32", S_PFLAGS, [cd[3]])
+        self.e("s_bitcmp1_b32", (), [cd[3], F_FIRST])
+        self.e("s_cselect_b64", S_EL, [S_ELC, 0])
+        self.e("s_bitcmp1_b32", (), [cd[3], F_LAST])
+        self.e("s_cselect_b64", S_ER, [S_ERC, 0])
+        self.e("s_bitcmp1_b32", (), [cd[3], F_ACTIVE])
+        self.e("s_cbranch_scc0", (), [lab])
+        gb = S(T[0].i, 2)
+        self.e("s_add_u32", gb[0], [S_GD[0], cd[0]])
+        self.e("s_addc_u32", gb[1], [S_GD[1], cd[1]])
+        if self.norm != 2:
+            up, dn = S(T[2].i, 2), S(T[4].i, 2)
+            # row below outside the image: read this row instead (zeroed when cooked); same for the row above
+            self.e("s_bitcmp1_b32", (), [cd[3], F_UP])
+            self.e("s_cselect_b32", T[6], [0, S_W4])
+            self.e("s_sub_u32", up[0], [gb[0], T[6]])
+            self.e("s_subb_u32", up[1], [gb[1], 0])
+            self.e("s_bitcmp1_b32", (), [cd[3], F_DN])
+            self.e("s_cselect_b32", T[6], [0, S_W4])
+            self.e("s_add_u32", dn[0], [gb[0], T[6]])
+            self.e("s_addc_u32", dn[1], [gb[1], 0])
+            bases = [up, up, up, gb, gb, dn, dn, dn]
+        else:
+            bases = [gb] * 8
+        for k in range(8):
+            self.e("global_load_dwordx2", PEND_G[k], [V_OFFK[k], bases[k]])
+        b1 = S(T[8].i, 2)
+        self.e("s_add_u32", b1[0], [S_BLUR[0], cd[2]])
+        self.e("s_addc_u32", b1[1], [S_BLUR[1], 0])
+        self.e("global_load_dwordx2", PEND_BLUR, [V_OFF1, b1])
+        if self.hin:
+            b2 = S(T[10].i, 2)
+            self.e("s_add_u32", b2[0], [S_HIN[0], cd[2]])
+            self.e("s_addc_u32", b2[1], [S_HIN[1], 0])
+            self.e("global_load_dwordx2", PEND_HIN, [V_OFF1, b2])
+        if self.sparse:
+            b3 = S(T[6].i, 2)
+            self.e("s_add_u32", b3[0], [S_SP[0], cd[2]])
+            self.e("s_addc_u32", b3[1], [S_SP[1], 0])
+            self.e("global_load_dwordx2", PEND_SP, [V_OFF1, b3])
+        self.p.label(lab)
+
+    def cook_event(self, g):
+        self.cook_pending(V_RINGW[g])
+        self.p.waitcnt(lgkm=0)     # the next task's descriptor (requested at the previous event)
+        self.issue_task(CD[g ^ 1])
+
+    # ---------------------------------------------------------------------------------- prologue
+    def prologue(self):
+        e = self.e
+        # zero LDS: 114688 bytes / 512 threads = 14 x 16 bytes per thread
+        e("v_lshlrev_b32", V_L16, [4, V_LANE])
+        e("v_lshlrev_b32", V_COL4, [2, V_LANE])
+        e("s_lshl_b32", T[0], [S_WV, 10])
+        e("s_add_i32", T[0], [T[0], S_LDSB])
+        e("v_add_u32", V_TMP, [T[0], V_L16])  # wave*1024 + lane*16 : 8 KB per sweep
+        for k in range(4):
+            self.mov(CK[k], 0)
+        e("v_add_u32", CK[4], [0x10000, V_TMP])
+        for i in range(14):
+            e("ds_write_b128", (), [V_TMP if i < 8 else CK[4], CK.sub(0, 4)], offset=(i & 7) * 8192)
+        # state
+        for r in range(ACC_BASE, WT_BASE + 144):
+            self.mov(V(r), 0)
+        for k in range(8):
+            self.mov(PEND_G[k][0], 0)
+            self.mov(PEND_G[k][1], 0)
+        for q in (PEND_BLUR, PEND_HIN, PEND_SP):
+            self.mov(q[0], 0)
+            self.mov(q[1], 0)
+        e("s_mov_b32", S_TAU, [0])
+        e("s_mov_b32", S_ACT, [0])
+        e("s_and_b32", T[1], [S_WV, 1])            # T1 = wave parity (= cooking half)
+        e("s_lshr_b32", T[2], [S_WV, 1])           # T2 = wv >> 1
+        # boundary exchange addresses
+        for p in (0, 1):
+            # buffer written in phase parity p: p ^ (wv & 1)
+            e("s_xor_b32", T[3], [T[1], p])
+            e("s_lshl_b32", T[4], [T[3], 14])          # written buffer * 16384
+            e("s_xor_b32", T[5], [T[4], 16384])        # read buffer
+            e("s_add_i32", T[4], [T[4], S_LDSB])
+            e("s_add_i32", T[5], [T[5], S_LDSB])
+            e("s_lshl_b32", T[6], [S_WV, 11])
+            e("s_add_i32", T[7], [T[4], T[6]])
+            e("v_add_u32", V_WR[p], [T[7], V_L16])
+            e("s_add_i32", T[6], [S_WV, 7])
+            e("s_and_b32", T[6], [T[6], 7])
+            e("s_lshl_b32", T[6], [T[6], 11])
+            e("s_add_i32", T[7], [T[5], T[6]])
+            e("s_add_i32", T[7], [T[7], 1024])
+            e("v_add_u32", V_RT[p], [T[7], V_L16])
+            e("s_add_i32", T[6], [S_WV, 1])
+            e("s_and_b32", T[6], [T[6], 7])
+            e("s_lshl_b32", T[6], [T[6], 11])
+            e("s_add_i32", T[7], [T[5], T[6]])
+            e("v_add_u32", V_RB[p], [T[7], V_L16])
+        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*160
+        e("s_mul_i32", T[3], [T[1], 4 * RING_SLOT])
+        e("s_add_i32", T[3], [T[3], LDS_RING])
+        e("s_add_i32", T[3], [T[3], S_LDSB])
+        e("v_mul_u32_u24", V_TMP, [160, V_LANE])
+        e("v_add_u32", V_RINGR, [T[3], V_TMP])
+        # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7, owner lane L = 32*(wv&1) + lane/2, pair = lane & 1;
+        # V_RINGW[x] serves gamma parity x ^ (wv & 1)
+        e("v_lshrrev_b32", V_TMP, [1, V_LANE])
+        e("s_lshl_b32", T[3], [T[1], 5])
+        e("v_add_u32", V_TMP, [T[3], V_TMP])
+        e("v_mul_u32_u24", V_TMP, [160, V_TMP])
+        e("v_and_b32", CK[0], [1, V_LANE])
+        e("v_lshlrev_b32", CK[0], [2, CK[0]])
+        e("v_add_u32", V_TMP, [V_TMP, CK[0]])
+        for x in (0, 1):
+            e("s_xor_b32", T[3], [T[1], x])            # gamma parity
+            e("s_lshl_b32", T[3], [T[3], 2])
+            e("s_add_i32", T[3], [T[3], T[2]])
+            e("s_add_i32", T[3], [T[3], 7])            # -1 mod 8
+            e("s_and_b32", T[3], [T[3], 7])
+            e("s_mul_i32", T[3], [T[3], RING_SLOT])
+            e("s_add_i32", T[3], [T[3], LDS_RING])
+            e("s_add_i32", T[3], [T[3], S_LDSB])
+            e("v_add_u32", V_RINGW[x], [T[3], V_TMP])
+        # global offsets of the lane's pixel pair: 4*xb = 512*(wv&1) + 8*lane
+        e("v_lshlrev_b32", V_OFF1, [3, V_LANE])
+        e("s_lshl_b32", T[3], [T[1], 9])
+        e("v_add_u32", V_OFF1, [T[3], V_OFF1])
+        for k in range(8):
+            e("s_mul_i32", T[3], [S_HW4, k])
+            if self.norm != 2:
+                if DY[k] > 0:
+                    e("s_add_i32", T[3], [T[3], S_W4])
+                if DY[k] < 0:
+                    e("s_sub_i32", T[3], [T[3], S_W4])
+                if DX[k] != 0:
+                    e("s_add_i32", T[3], [T[3], 4 * DX[k]])
+            e("v_add_u32", V_OFFK[k], [T[3], V_OFF1])
+        # constant edge-lane masks
+        e("s_cmp_eq_u32", (), [T[1], 0])
+        e("s_cselect_b32", S_ELC[0], [1, 0])
+        e("s_mov_b32", S_ELC[1], [0])
+        e("s_mov_b32", S_ERC[0], [0])
+        e("s_cselect_b32", S_ERC[1], [0, 0x80000000])
+        # ring counters: wave 7's slot 3 fires at step 0 for the (inactive) row -1
+        e("s_lshl_b32", S_QB, [S_WV, 2])
+        e("s_cmp_eq_u32", (), [S_WV, 7])
+        e("s_cselect_b32", S_QB, [-4, S_QB])
+        # cooking pipeline: task n = row 4n - 1 + (wv>>1), half wv&1.  Task 0 is cooked synchronously, task 1 requested,
+        # the descriptor of task 2 fetched (both buffers: the first loop event reads either one, by wave parity)
+        e("s_add_i32", S_PQ, [T[2], -1])
+        self.desc_offset(T[0], S_PQ, 0)
+        e("s_load_dwordx8", CD[0], [S_PLAN, T[0]])
+        e("s_add_i32", S_PQ, [S_PQ, 4])
+        self.desc_offset(T[0], S_PQ, 0)
+        e("s_load_dwordx8", CD[1], [S_PLAN, T[0]])
+        self.p.waitcnt(lgkm=0)
+        self.issue_task(CD[0])
+        e("s_barrier")                               # LDS zero-fill complete before anyone cooks into it
+        # gamma = 0 has parity 0: ring address V_RINGW[0 ^ (wv & 1)]
+        e("s_and_b32", T[1], [S_WV, 1])
+        e("s_cmp_eq_u32", (), [T[1], 0])
+        e("s_cselect_b64", S(T[4].i, 2), [-1, 0])
+        e("v_cndmask_b32", V_TMP, [V_RINGW[1], V_RINGW[0], S(T[4].i, 2)])
+        self.cook_pending(V_TMP)
+        self.issue_task(CD[1])
+        e("s_add_i32", S_PQ, [S_PQ, 4])
+        self.desc_offset(T[0], S_PQ, 0)
+        e("s_load_dwordx8", CD[0], [S_PLAN, T[0]])
+        e("s_load_dwordx8", CD[1], [S_PLAN, T[0]])
+        # event descriptors for the waves that start inside their event window (wave 0: slot 0, wave 7: slot 3)
+        self.prefetch_event(0)
+        self.prefetch_event(3)
+        self.p.waitcnt(lgkm=0)
+        e("s_barrier")
+        for w in range(NW):
+            c0 = (LV - 3 * w) % LV
+            e("s_cmp_eq_u32", (), [S_WV, w])
+            e("s_cbranch_scc1", (), [".LS%d_%%=" % c0])
+
+    def build(self):
+        self.prologue()
+        for c in range(LV):
+            self.step(c)
+        self.p.label(".Lexit_%=")
+        return self.p
+
+
+def build(cfg, sched=True):
+    g = Gen(cfg)
+    p = g.build()
+    if sched:
+        schedule(p)
+    errs = check_hazards(p)
+    if errs:
+        raise RuntimeError("hazards:\n" + "\n".join(errs[:20]))
+    return p

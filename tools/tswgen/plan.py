@@ -1,0 +1,93 @@
+"""tools/tswgen/plan.py -- reference (numpy) version of the row-descriptor table that cspn2d_plan_kernel builds on the
+device: which image rows a workgroup streams, in which order, and what it does with each (cook flags, output range).
+Mirrors tools/tsw_model.py's planner except that the last band is shifted left to end exactly at the image edge, so that
+every band is 256 real columns wide."""
+import numpy as np
+
+from .kernel import PADF, PADB, F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED
+
+BW = 256
+
+
+def halo_of(n_iter):
+    return 4 * ((n_iter + 3) // 4)
+
+
+def plan_bands(W, n_iter):
+    assert W >= BW and W % 4 == 0
+    h = halo_of(n_iter)
+    bands, lo = [], 0
+    while True:
+        p0 = 0 if lo == 0 else lo - h
+        if p0 + BW >= W:
+            bands.append((W - BW, lo, W))
+            break
+        hi = p0 + BW - h
+        bands.append((p0, lo, hi))
+        lo = hi
+    return bands
+
+
+def share_segments(B, H, W, n_iter, bands, g, n_wg):
+    total = B * len(bands) * H
+    r0, r1 = g * total // n_wg, (g + 1) * total // n_wg
+    segs, r = [], r0
+    while r < r1:
+        u, y0 = divmod(r, H)
+        y1 = min(H, y0 + (r1 - r))
+        b, bi = divmod(u, len(bands))
+        segs.append((b, bi, max(0, y0 - n_iter), min(H, y1 + n_iter), y0, y1))
+        r += y1 - y0
+    return segs
+
+
+def stream_of(segs):
+    rows = []
+    for i, s in enumerate(segs):
+        if i:
+            rows.append(None)
+        rows.extend((i, y) for y in range(s[2], s[3]))
+    return rows
+
+
+def max_stream(B, H, W, n_iter, n_wg):
+    nb = len(plan_bands(W, n_iter))
+    total = B * nb * H
+    share = -(-total // n_wg)
+    nseg = share // H + 2
+    return share + nseg * (2 * n_iter + 1)
+
+
+def build_plan(B, H, W, n_iter, n_wg):
+    """-> (header int32[n_wg][4] = Q, last_step, 0, 0 ; table uint32[n_wg][stride][8])"""
+    bands = plan_bands(W, n_iter)
+    stride = PADF + max_stream(B, H, W, n_iter, n_wg) + PADB
+    hdr = np.zeros((n_wg, 4), np.int32)
+    tab = np.zeros((n_wg, stride, 8), np.uint32)
+    for g in range(n_wg):
+        segs = share_segments(B, H, W, n_iter, bands, g, n_wg)
+        rows = stream_of(segs)
+        Q = len(rows)
+        assert PADF + Q + PADB <= stride
+        hdr[g, 0] = Q
+        hdr[g, 1] = (3 * ((Q - 1) >> 2) + ((Q - 1) & 3) + n_iter) if Q else -1
+        for q, r in enumerate(rows):
+            if r is None:
+                continue
+            si, y = r
+            b, bi, ys, ye, y0, y1 = segs[si]
+            p0, lo, hi = bands[bi]
+            goff = 4 * (b * 8 * H * W + y * W + p0)
+            boff = 4 * (b * H * W + y * W + p0)
+            flags = (1 << F_ACTIVE) | ((y + 1 < H) << F_UP) | ((y >= 1) << F_DN) | ((p0 == 0) << F_FIRST) | \
+                    ((p0 + BW == W) << F_LAST) | ((y0 <= y < y1) << F_OWNED)
+            d = tab[g, PADF + q]
+            d[0] = goff & 0xffffffff
+            d[1] = goff >> 32
+            d[2] = boff
+            d[3] = flags
+            d[4] = 0
+            d[5] = (lo - p0) | ((hi - p0) << 16)
+            d[6] = y
+            d[7] = p0
+    return hdr, tab

@@ -1,0 +1,144 @@
+"""tools/tswgen/run_emu.py -- run the generated kernel in the CPU emulator against the oracle.
+usage: python -m tools.tswgen.run_emu [B H W n_wg norm sparse hin seed]"""
+import sys
+import time
+
+import numpy as np
+
+from . import kernel as K
+from .emu import Emu, EmuError
+from .plan import build_plan
+
+
+def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True):
+    sys.path.insert(0, ".")
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((B, 8, H, W)).astype(np.float32)
+    if norm == 2:
+        g = np.abs(g)
+        g /= g.sum(1, keepdims=True) + 0.3
+    blur = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
+    sp = None
+    if sparse:
+        m = rng.random((B, 1, H, W)) < 0.05
+        sp = (m * (rng.random((B, 1, H, W)) * 10 + 0.1)).astype(np.float32)
+    if zero_patch:
+        g[:, :, H // 2:H // 2 + 3, 40:48] = 0
+    n_iter = 24
+    hinv = None
+    if hin:  # emulate a second pass: level-0 values differ from blur
+        hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin), sched=sched)
+    hdr, tab = build_plan(B, H, W, n_iter, n_wg)
+    # global memory image
+    def al(n):
+        return (n + 4095) // 4096 * 4096
+    off, cur = {}, 8192
+    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("out", np.zeros_like(blur)), ("plan", tab)):
+        if arr is None:
+            off[name] = 4096
+            continue
+        off[name] = cur
+        cur += al(arr.nbytes) + 4096
+    mem = np.zeros(cur + 4096, np.uint8)
+    mem.view(np.float32)[:] = np.nan
+    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("plan", tab)):
+        if arr is not None:
+            mem[off[name]:off[name] + arr.nbytes] = arr.view(np.uint8).ravel()
+    t0 = time.time()
+    tot = 0
+    icount = {}
+    for wg in range(n_wg):
+        if hdr[wg, 0] == 0:
+            continue
+        emu = Emu(prog, mem, K.LDS_BYTES)
+        for w in emu.waves:
+            w.v[0] = np.arange(64, dtype=np.uint32)
+            def set64(r, val):
+                w.s[r.i] = val & 0xffffffff
+                w.s[r.i + 1] = val >> 32
+            set64(K.S_GD, off["gd"])
+            set64(K.S_BLUR, off["blur"])
+            set64(K.S_HIN, off["hin"])
+            set64(K.S_SP, off["sp"])
+            set64(K.S_OUT, off["out"])
+            set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 32)
+            w.s[K.S_W4.i] = 4 * W
+            w.s[K.S_HW4.i] = 4 * H * W
+            w.s[K.S_LAST.i] = int(hdr[wg, 1])
+            w.s[K.S_WV.i] = w.wid
+        tot += emu.run()
+        for w in emu.waves:
+            for k, v in w.icount.items():
+                icount[k] = icount.get(k, 0) + v
+    out = mem[off["out"]:off["out"] + blur.nbytes].view(np.float32).reshape(blur.shape)
+    if hin:
+        # oracle for a continuation pass: propagate hinv with blur as H0 ... the oracle has no such entry; emulate with numpy
+        ref = ref_hin(g, blur, sp, hinv, n_iter, norm)
+    else:
+        ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none"][norm])
+    nanmis = np.isnan(out) != np.isnan(ref)
+    den = np.nanmax(np.abs(ref))
+    err = np.nanmax(np.abs(out - ref)) / den if not nanmis.any() else np.inf
+    if verbose:
+        steps = int(hdr[:, 1].max()) + 1
+        print("B%d H%d W%d wg%d norm%d sp%d hin%d: rel err %.3g  nan mismatch %d  (%d instr, %.1fs, %d NaNs in ref)" % (
+            B, H, W, n_wg, norm, sparse, hin, err, nanmis.sum(), tot, time.time() - t0, np.isnan(ref).sum()))
+        nv = sum(v for k, v in icount.items() if k.startswith("v_"))
+        ns = sum(v for k, v in icount.items() if k.startswith("s_") and k not in ("s_waitcnt", "s_barrier", "s_nop"))
+        nn = icount.get("s_nop", 0)
+        nm = sum(v for k, v in icount.items() if k.startswith("ds_") or k.startswith("global_"))
+        print("   per wave-step: VALU %.1f SALU %.1f nop %.1f mem %.1f (steps %d)" % (
+            nv / 8 / steps / n_wg, ns / 8 / steps / n_wg, nn / 8 / steps / n_wg, nm / 8 / steps / n_wg, steps))
+    return err, nanmis.sum(), out, ref
+
+
+def ref_hin(g, blur, sp, hin, n_iter, norm):
+    """numpy reference for a continuation pass (H_t starts at hin, H0 = blur), restating oracle/cspn_oracle.c"""
+    B, _, H, W = g.shape
+    DY, DX = K.DY, K.DX
+    gp = np.abs(g) if norm == 1 else g
+    G = np.zeros_like(g)
+    for k in range(8):
+        if norm == 2:
+            G[:, k] = gp[:, k]
+        else:
+            pad = np.zeros((B, H + 2, W + 2), np.float32)
+            pad[:, 1:-1, 1:-1] = gp[:, k]
+            G[:, k] = pad[:, 1 + DY[k]:1 + DY[k] + H, 1 + DX[k]:1 + DX[k] + W]
+    with np.errstate(all="ignore"):
+        if norm == 2:
+            w = G
+            gs = None
+        else:
+            w = G / np.abs(G).sum(1, keepdims=True)
+            gs = w.sum(1, keepdims=True)
+        h = hin.copy()
+        m = np.sign(sp) if sp is not None else None
+        for _ in range(n_iter):
+            pad = np.zeros((B, H + 2, W + 2), np.float32)
+            pad[:, 1:-1, 1:-1] = h[:, 0]
+            acc = np.zeros_like(h)
+            for k in range(8):
+                acc[:, 0] += w[:, k] * pad[:, 1 + DY[k]:1 + DY[k] + H, 1 + DX[k]:1 + DX[k] + W]
+            if gs is not None:
+                acc = (1 - gs) * blur + acc
+            if m is not None:
+                acc = (1 - m) * acc + m * blur
+            h = acc.astype(np.float32)
+    return h
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    B, H, W, n_wg = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (1, 12, 256, 1)
+    norm = int(a[4]) if len(a) > 4 else 0
+    sparse = bool(int(a[5])) if len(a) > 5 else False
+    hin = bool(int(a[6])) if len(a) > 6 else False
+    seed = int(a[7]) if len(a) > 7 else 0
+    try:
+        run_case(B, H, W, n_wg, norm, sparse, hin, seed)
+    except EmuError as ex:
+        print("EMU ERROR:", ex)
+        sys.exit(1)
