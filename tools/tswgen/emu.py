@@ -407,6 +407,13 @@ class Emu(object):
                     a, b = rv(w, s[0]).astype(np.int64), rv(w, s[1]).astype(np.int64)
                 r = {"eq": a == b, "gt": a > b, "ge": a >= b, "lt": a < b, "le": a <= b}[kind] & ex
                 self.ws64(w, d[0], int(_bool_to_mask(r)))
+            elif o == "v_readfirstlane_b32":
+                lanes = np.nonzero(ex)[0]
+                self.ws(w, d[0], int(rv(w, s[0])[lanes[0] if len(lanes) else 0]))
+            elif o == "v_swap_b32":
+                a, b = rv(w, s[0]).copy(), rv(w, s[1]).copy()
+                self.wv(w, d[0], a)
+                self.wv(w, d[1], b)
             elif o == "v_lshlrev_b32":
                 self.wv(w, d[0], (rv(w, s[1]).astype(np.uint64) << np.uint64(self.rs(w, s[0]) & 31)).astype(U32))
             elif o == "v_lshrrev_b32":

@@ -187,6 +187,8 @@ class I(object):
             return "%s %s, %s, %s" % (o, optext(d[0]), optext(s[0]), optext(s[1]))
         if o.startswith("s_cmp") or o.startswith("s_bitcmp"):
             return "%s %s, %s" % (o, optext(s[0]), optext(s[1]))
+        if o == "v_swap_b32":
+            return "v_swap_b32 %s, %s" % (optext(d[0]), optext(d[1]))
         if o == "v_mov_b32" and self.is_dpp():
             return "v_mov_b32_dpp %s, %s %s row_mask:0xf bank_mask:0xf bound_ctrl:1" % (optext(d[0]), optext(s[0]), m["dpp"])
         if o in VOP_PK:

@@ -16,9 +16,11 @@ from .isa import Prog, V, S, EXEC, schedule, check_hazards
 
 NW, NSLOT, LV = 8, 4, 24
 PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
-DESC_BYTES = 32
+DESC_BYTES = 16              # goff_lo, goff_hi, boff, flags | lo << 8 | hi << 20
 LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 10240
-LDS_BYTES = LDS_RING + 8 * RING_SLOT
+LDS_TAB = LDS_RING + 8 * RING_SLOT   # the workgroup's row-descriptor table, copied from global memory by the prologue
+TAB_MAX_ROWS = 3072
+LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES   # 160 KB
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
 
@@ -33,6 +35,7 @@ V_RINGW = [V(10), V(11)]
 V_OFFK = [V(12 + k) for k in range(8)]
 V_OFF1 = V(20)
 V_TMP = V(21)
+V_DE, V_DO, V_DC = V(21), V(22, 2), V(252, 4)  # descriptor fetches (event: new row's d3, old row's d2:d3; cooking: whole row)
 TQ, BQ, TA, TB, HN, HA, OUTQ = V(24, 4), V(28, 4), V(32, 4), V(36, 4), V(40, 4), V(44, 4), V(48, 4)
 CK = V(24, 28)  # cooking temporaries alias the step temporaries
 PEND_G = [V(52 + 2 * k, 2) for k in range(8)]
@@ -52,13 +55,16 @@ def WT(j, k):
 S_GD, S_BLUR, S_HIN, S_SP, S_OUT, S_PLAN = S(16, 2), S(18, 2), S(20, 2), S(22, 2), S(24, 2), S(26, 2)
 S_W4, S_HW4, S_LAST, S_WV = S(28), S(29), S(30), S(31)
 S_LDSB = S(15)  # LDS base address of the kernel's __shared__ block
+S_NROWS = S(14)  # descriptors in this workgroup's table (<= TAB_MAX_ROWS)
 S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(32), S(33), S(34), S(35), S(36)
 S_EL, S_ER = S(38, 2), S(40, 2)
-EN_F = [S(44), S(45)]           # new row's flags, per event-slot parity
-EO = [S(48, 4), S(52, 4)]       # retiring row's descriptor dwords 2..5 (boff, flags, -, lohi)
-CD = [S(60, 8), S(84, 8)]       # cooking descriptors (double buffered)
+S_ENF = S(44)                   # event: the entering row's descriptor dword 3 (flags)
+S_EO = S(48, 2)                 # event: the retiring row's descriptor dwords 2:3 (boff, flags | lo | hi)
+S_CD = S(60, 4)                 # cooking: descriptor of the task being requested
+S_TABB = S(37)                  # LDS address of descriptor row 0 (table base + PADF rows)
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
 S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
+GB_UP, GB_MID, GB_DN, B_BLUR, B_HIN, B_SP = S(0, 2), S(2, 2), S(4, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task
 
 
 class Gen(object):
@@ -67,12 +73,16 @@ class Gen(object):
         self.p = Prog()
         self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
         assert cfg.get("n_iter", 24) == 24
+        self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
 
     # ---------------------------------------------------------------------------------- small helpers
     def e(self, op, dst=(), src=(), **m):
         return self.p.emit(op, dst, src, **m)
 
     def fma(self, d, a, b, c, **m):
+        keep = m.pop("keep", False)
+        if "nostep" in self.ab and not keep:
+            return
         self.e("v_pk_fma_f32", d, [a, b, c], **m)
 
     def mov(self, d, s):
@@ -80,6 +90,8 @@ class Gen(object):
 
     def shift(self, q, t):
         """q = (c0,c2,c1,c3); t <- xl=(c3 of lane-1, c1), xr=(c2, c0 of lane+1)"""
+        if "nostep" in self.ab:
+            return
         self.e("v_mov_b32", t[0], q[3], dpp="wave_shr:1")
         self.e("v_mov_b32", t[3], q[0], dpp="wave_shl:1")
         self.mov(t[1], q[2])
@@ -115,31 +127,45 @@ class Gen(object):
         for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
             self.mov(q[k], 0)
 
-    def desc_offset(self, dst, qreg, add):
-        """dst <- byte offset of descriptor (qreg + add) in the plan table"""
-        self.e("s_add_i32", dst, [qreg, add + PADF])
-        self.e("s_lshl_b32", dst, [dst, 5])
+    def desc_addr(self, dst, qreg, add):
+        """dst <- LDS address of the descriptor of stream row (qreg + add)"""
+        self.e("s_add_i32", dst, [qreg, add])
+        self.e("s_lshl_b32", dst, [dst, 4])
+        self.e("s_add_i32", dst, [dst, S_TABB])
 
     # ---------------------------------------------------------------------------------- events
-    def prefetch_event(self, ev):
-        """scalar loads for the event of slot ev (issued one step ahead)"""
-        st = ev & 1
-        self.desc_offset(T[0], S_QB, ev)
-        self.e("s_add_i32", T[1], [T[0], 12])
-        self.e("s_load_dword", EN_F[st], [S_PLAN, T[1]])
-        self.e("s_add_i32", T[1], [T[0], 8 - 32 * DESC_BYTES])
-        self.e("s_load_dwordx4", EO[st], [S_PLAN, T[1]])
+    def fetch_event(self, ev):
+        """LDS reads of the descriptors the event of slot ev needs (issued with the boundary-row reads)"""
+        self.desc_addr(T[0], S_QB, ev)
+        self.mov(V_DE, T[0])
+        self.e("ds_read_b32", V_DE, [V_DE], offset=12)
+        self.e("s_add_i32", T[1], [T[0], -32 * DESC_BYTES])
+        self.mov(V_DO[0], T[1])
+        self.e("ds_read_b64", V_DO, [V_DO[0]], offset=8)
+
+    def fetch_cook(self):
+        self.desc_addr(T[2], S_PQ, 0)
+        self.mov(V_DC[0], T[2])
+        self.e("ds_read_b128", V_DC, [V_DC[0]])
+
+    def take_event(self):
+        self.e("v_readfirstlane_b32", S_ENF, [V_DE])
+        self.e("v_readfirstlane_b32", S_EO[0], [V_DO[0]])
+        self.e("v_readfirstlane_b32", S_EO[1], [V_DO[1]])
+
+    def take_cook(self):
+        for k in range(4):
+            self.e("v_readfirstlane_b32", S_CD[k], [V_DC[k]])
 
     def retire(self, j, vq):
-        st = j & 1
-        eo = EO[st]
+        eo = S_EO
         lab = self.p.newlabel("noret")
         self.e("s_bitcmp1_b32", (), [S_ACT, j])
         self.e("s_cbranch_scc0", (), [lab])
         self.e("s_bitcmp1_b32", (), [eo[1], F_OWNED])
         self.e("s_cbranch_scc0", (), [lab])
-        self.e("s_and_b32", T[2], [eo[3], 0xffff])
-        self.e("s_lshr_b32", T[3], [eo[3], 16])
+        self.e("s_bfe_u32", T[2], [eo[1], 8 | (9 << 16)])
+        self.e("s_bfe_u32", T[3], [eo[1], 20 | (9 << 16)])
         self.e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
         self.e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
         self.e("s_and_b64", S(T[4].i, 2), [S(T[4].i, 2), S(T[6].i, 2)])
@@ -155,13 +181,15 @@ class Gen(object):
         self.p.label(lab)
 
     def inject(self, j, vq):
-        st = j & 1
         for k in range(9):
-            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 16)
-        for k in (0, 3, 2, 1):
-            self.mov(vq[k], HN[k])
+            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 1024)
+        # the ring holds image order (c0,c1,c2,c3); registers hold (c0,c2,c1,c3)
+        self.mov(vq[0], HN[0])
+        self.mov(vq[3], HN[3])
+        self.mov(vq[2], HN[1])
+        self.mov(vq[1], HN[2])
         self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
-        self.e("s_bitcmp1_b32", (), [EN_F[st], F_ACTIVE])
+        self.e("s_bitcmp1_b32", (), [S_ENF, F_ACTIVE])
         self.e("s_cselect_b32", T[2], [1 << j, 0])
         self.e("s_or_b32", S_ACT, [S_ACT, T[2]])
         if j == 3:
@@ -180,24 +208,39 @@ class Gen(object):
         N1 = [ACC(p, j) for j in range(4)]
         N2 = [ACC(p ^ 1, j) for j in range(4)]
         ev = c if c < 4 else None
-        nxt_ev = (c + 1) % LV if (c + 1) % LV < 4 else None
+        if "noevents" in self.ab:
+            ev = None
+        cook = c % 3 == 2 and "nocook" not in self.ab
         self.p.label(".LS%d_%%=" % c)
         if ev is not None:
-            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 16)
+            self.fetch_event(ev)
+        if cook:
+            self.fetch_cook()
+        if ev is not None:
+            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 1024)
             if ev > 0:
-                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 16)
-        self.e("ds_read_b128", BQ, [V_RB[p]])
-        self.e("ds_read_b128", TQ, [V_RT[p]])
-        self.p.waitcnt(lgkm=0)
-        # scalar prefetches whose latency hides behind this step
-        if nxt_ev is not None:
-            self.prefetch_event(nxt_ev)
-        if c % 3 == 2:
+                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 1024)
+        if "nolds" not in self.ab:
+            self.e("ds_read_b128", BQ, [V_RB[p]])
+            self.e("ds_read_b128", TQ, [V_RT[p]])
+        loads = []
+        if cook:
+            # normalise + fold the pending task while the boundary rows arrive; its successor's inputs are requested
+            # in small groups between the FMAs of this step (a burst of loads would stall every wave at once)
             g = ((c + 1) // 3) & 1
+            self.cook_pending(V_RINGW[g])
+        self.p.waitcnt(lgkm=0)
+        if ev is not None:
+            self.take_event()
+        if cook:
+            self.take_cook()
+            self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
-            self.desc_offset(T[0], S_PQ, 0)
-            self.e("s_load_dwordx8", CD[g], [S_PLAN, T[0]])
+            loads = self.load_list()
+        nl = len(loads)
+        cuts = [0, (nl + 4) // 5, (2 * nl + 4) // 5, (3 * nl + 4) // 5, (4 * nl + 4) // 5, nl]
         # received boundary rows
+        self.issue_loads(loads[cuts[0]:cuts[1]])
         self.shift(BQ, TA)
         self.push_below(3, BQ, TA, N1[3])
         self.shift(TQ, TB)
@@ -209,19 +252,23 @@ class Gen(object):
             if ev == j:
                 self.retire(j, vq)
                 self.inject(j, vq)
-            else:
+            elif "noact" not in self.ab:
                 self.act_check(j, vq)
-            if j == 3:
+            self.issue_loads(loads[cuts[4 - j]:cuts[5 - j]])
+            if j == 3 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024)
-            if j == 0:
+            if j == 0 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=0)
             self.shift(vq, tq)
             if j > 0:
                 self.push_below(j - 1, vq, tq, N1[j - 1])
             if ev == j:
                 self.p.waitcnt(lgkm=0)  # the new coefficients
+                for k in range(9):
+                    self.e("v_swap_b32", [WT(j, k)[1], WT(j, k)[2]], [WT(j, k)[2], WT(j, k)[1]])
                 self.push_self(j, vq, tq, N2[j], init=WT(j, 8))
                 if j > 0:
+                    self.e("v_swap_b32", [HA[1], HA[2]], [HA[2], HA[1]])
                     self.shift(HA, OUTQ)
                     self.push_above(j, HA, OUTQ, N2[j])
             elif j > 0:
@@ -230,11 +277,10 @@ class Gen(object):
                 self.push_self(0, vq, tq, N2[0], init=WT(0, 8))
             if j < 3:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
-        if c % 3 == 2:
-            self.cook_event(((c + 1) // 3) & 1)
         self.e("s_add_i32", S_TAU, [S_TAU, 1])
         self.p.waitcnt(lgkm=0)
-        self.e("s_barrier")
+        if "nobar" not in self.ab:
+            self.e("s_barrier")
         self.e("s_cmp_gt_u32", (), [S_TAU, S_LAST])
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
         if c == LV - 1:
@@ -246,7 +292,10 @@ class Gen(object):
         g = PEND_G
         norm = self.norm
         l_inact, l_done = self.p.newlabel("cinact"), self.p.newlabel("cdone")
-        self.p.waitcnt(vm=0)
+        if "nocookwait" not in self.ab:
+            self.p.waitcnt(vm=0)
+        if "nocookmath" in self.ab:
+            return
         self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_ACTIVE])
         self.e("s_cbranch_scc0", (), [l_inact])
         if norm != 2:
@@ -268,10 +317,11 @@ class Gen(object):
                     self.e("v_cndmask_b32", g[k][1], [g[k][1], 0, S_ER])
             self.p.label(lab)
         # temporaries
-        sx, sy = CK[0], CK[1]
-        tt, scale, cc, t2 = CK.sub(2, 2), CK.sub(4, 2), CK.sub(6, 2), CK.sub(8, 2)
-        ex, ey = CK[10], CK[11]
-        mm, om = CK.sub(12, 2), CK.sub(14, 2)
+        # (the boundary rows are arriving in TQ / BQ / HN / HA: only TA, TB and OUTQ are free here)
+        sx, sy = TA[0], TA[1]
+        tt, scale, cc, t2 = TA.sub(2, 2), TB.sub(0, 2), TB.sub(2, 2), OUTQ.sub(0, 2)
+        ex, ey = t2[0], t2[1]          # dead before t2 is formed
+        mm, om = TA.sub(0, 2), TA.sub(2, 2)  # sparse only: reuse sx,sy / tt once they are dead
         h0 = PEND_BLUR
         if norm == 1:
             for k in range(8):
@@ -299,7 +349,7 @@ class Gen(object):
                 self.mov(tt[0], sx)
                 self.mov(tt[1], sy)
                 self.e("v_pk_mul_f32", t2, [tt, scale])
-            self.fma(cc, t2, h0, h0, neg_lo=[1, 0, 0], neg_hi=[1, 0, 0])  # (1 - sigma) * H0
+            self.fma(cc, t2, h0, h0, neg_lo=[1, 0, 0], neg_hi=[1, 0, 0], keep=True)  # (1 - sigma) * H0
         else:
             self.mov(cc[0], 0)
             self.mov(cc[1], 0)
@@ -318,70 +368,82 @@ class Gen(object):
                 self.mov(scale[0], om[0])
                 self.mov(scale[1], om[1])
             self.e("v_pk_mul_f32", t2, [mm, h0])
-            self.fma(cc, om, cc, t2)
+            self.fma(cc, om, cc, t2, keep=True)
+        nw = "nocookwrite" in self.ab
         for k in range(8):
             if norm != 2 or self.sparse:
                 self.e("v_pk_mul_f32", g[k], [g[k], scale])
-            self.e("ds_write2_b32", (), [ringw, g[k][0], g[k][1]], offset0=4 * k, offset1=4 * k + 2)
-        self.e("ds_write2_b32", (), [ringw, cc[0], cc[1]], offset0=32, offset1=34)
+            if not nw:
+                self.e("ds_write_b64", (), [ringw, g[k]], offset=k * 1024)
         hv = PEND_HIN if self.hin else PEND_BLUR
-        self.e("ds_write2_b32", (), [ringw, hv[0], hv[1]], offset0=36, offset1=38)
+        if not nw:
+            self.e("ds_write_b64", (), [ringw, cc], offset=8 * 1024)
+            self.e("ds_write_b64", (), [ringw, hv], offset=9 * 1024)
         self.e("s_branch", (), [l_done])
         self.p.label(l_inact)
-        self.mov(CK[0], 0)
+        self.mov(OUTQ[0], 0)
+        self.mov(OUTQ[1], 0)
         for k in range(10):
-            self.e("ds_write2_b32", (), [ringw, CK[0], CK[0]], offset0=4 * k, offset1=4 * k + 2)
+            self.e("ds_write_b64", (), [ringw, OUTQ.sub(0, 2)], offset=k * 1024)
         self.p.label(l_done)
 
-    def issue_task(self, cd):
-        """request the inputs of the task described by descriptor registers cd; it becomes the pending task"""
-        lab = self.p.newlabel("noload")
+    def issue_prepare(self, cd):
+        """scalar side of a task request: flags, edge-lane masks and the base addresses of its rows (kept in s0..s11 so that
+        the loads themselves can be spread over the following step)"""
         self.e("s_mov_b32", S_PFLAGS, [cd[3]])
         self.e("s_bitcmp1_b32", (), [cd[3], F_FIRST])
         self.e("s_cselect_b64", S_EL, [S_ELC, 0])
         self.e("s_bitcmp1_b32", (), [cd[3], F_LAST])
         self.e("s_cselect_b64", S_ER, [S_ERC, 0])
-        self.e("s_bitcmp1_b32", (), [cd[3], F_ACTIVE])
-        self.e("s_cbranch_scc0", (), [lab])
-        gb = S(T[0].i, 2)
-        self.e("s_add_u32", gb[0], [S_GD[0], cd[0]])
-        self.e("s_addc_u32", gb[1], [S_GD[1], cd[1]])
+        self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[0]])
+        self.e("s_addc_u32", GB_MID[1], [S_GD[1], cd[1]])
         if self.norm != 2:
-            up, dn = S(T[2].i, 2), S(T[4].i, 2)
-            # row below outside the image: read this row instead (zeroed when cooked); same for the row above
-            self.e("s_bitcmp1_b32", (), [cd[3], F_UP])
-            self.e("s_cselect_b32", T[6], [0, S_W4])
-            self.e("s_sub_u32", up[0], [gb[0], T[6]])
-            self.e("s_subb_u32", up[1], [gb[1], 0])
-            self.e("s_bitcmp1_b32", (), [cd[3], F_DN])
-            self.e("s_cselect_b32", T[6], [0, S_W4])
-            self.e("s_add_u32", dn[0], [gb[0], T[6]])
-            self.e("s_addc_u32", dn[1], [gb[1], 0])
-            bases = [up, up, up, gb, gb, dn, dn, dn]
-        else:
-            bases = [gb] * 8
-        for k in range(8):
-            self.e("global_load_dwordx2", PEND_G[k], [V_OFFK[k], bases[k]])
-        b1 = S(T[8].i, 2)
-        self.e("s_add_u32", b1[0], [S_BLUR[0], cd[2]])
-        self.e("s_addc_u32", b1[1], [S_BLUR[1], 0])
-        self.e("global_load_dwordx2", PEND_BLUR, [V_OFF1, b1])
+            # row below / above outside the image: read this row instead (zeroed when cooked).  An inactive row has an
+            # all-zero descriptor: it loads (and ignores) the first rows of the tensors, so it must not be clamped.
+            self.e("s_bitcmp1_b32", (), [cd[3], F_ACTIVE])
+            self.e("s_cselect_b32", T[6], [cd[3], (1 << F_UP) | (1 << F_DN)])
+            self.e("s_bitcmp1_b32", (), [T[6], F_UP])
+            self.e("s_cselect_b32", T[7], [0, S_W4])
+            self.e("s_sub_u32", GB_UP[0], [GB_MID[0], T[7]])
+            self.e("s_subb_u32", GB_UP[1], [GB_MID[1], 0])
+            self.e("s_bitcmp1_b32", (), [T[6], F_DN])
+            self.e("s_cselect_b32", T[7], [0, S_W4])
+            self.e("s_add_u32", GB_DN[0], [GB_MID[0], T[7]])
+            self.e("s_addc_u32", GB_DN[1], [GB_MID[1], 0])
+        self.e("s_add_u32", B_BLUR[0], [S_BLUR[0], cd[2]])
+        self.e("s_addc_u32", B_BLUR[1], [S_BLUR[1], 0])
         if self.hin:
-            b2 = S(T[10].i, 2)
-            self.e("s_add_u32", b2[0], [S_HIN[0], cd[2]])
-            self.e("s_addc_u32", b2[1], [S_HIN[1], 0])
-            self.e("global_load_dwordx2", PEND_HIN, [V_OFF1, b2])
+            self.e("s_add_u32", B_HIN[0], [S_HIN[0], cd[2]])
+            self.e("s_addc_u32", B_HIN[1], [S_HIN[1], 0])
         if self.sparse:
-            b3 = S(T[6].i, 2)
-            self.e("s_add_u32", b3[0], [S_SP[0], cd[2]])
-            self.e("s_addc_u32", b3[1], [S_SP[1], 0])
-            self.e("global_load_dwordx2", PEND_SP, [V_OFF1, b3])
-        self.p.label(lab)
+            self.e("s_add_u32", B_SP[0], [S_SP[0], cd[2]])
+            self.e("s_addc_u32", B_SP[1], [S_SP[1], 0])
 
-    def cook_event(self, g):
-        self.cook_pending(V_RINGW[g])
-        self.p.waitcnt(lgkm=0)     # the next task's descriptor (requested at the previous event)
-        self.issue_task(CD[g ^ 1])
+    def load_list(self):
+        if "nocookload" in self.ab:
+            return []
+        bases = [GB_MID] * 8 if self.norm == 2 else [GB_UP, GB_UP, GB_UP, GB_MID, GB_MID, GB_DN, GB_DN, GB_DN]
+        items = [(PEND_G[k], V_OFFK[k], bases[k]) for k in range(8)]
+        if "alignedloads" in self.ab:
+            items = [(PEND_G[k], V_OFF1, bases[k]) for k in range(8)]
+        if "halfloads" in self.ab:
+            items = items[:4]
+        if "sameload" in self.ab:
+            items = [(PEND_G[k], V_OFFK[k], S_GD) for k in range(8)]
+        items.append((PEND_BLUR, V_OFF1, B_BLUR))
+        if self.hin:
+            items.append((PEND_HIN, V_OFF1, B_HIN))
+        if self.sparse:
+            items.append((PEND_SP, V_OFF1, B_SP))
+        return items
+
+    def issue_loads(self, items):
+        for dst, voff, base in items:
+            self.e("global_load_dwordx2", dst, [voff, base])
+
+    def issue_task(self, cd):
+        self.issue_prepare(cd)
+        self.issue_loads(self.load_list())
 
     # ---------------------------------------------------------------------------------- prologue
     def prologue(self):
@@ -432,21 +494,16 @@ class Gen(object):
             e("s_lshl_b32", T[6], [T[6], 11])
             e("s_add_i32", T[7], [T[5], T[6]])
             e("v_add_u32", V_RB[p], [T[7], V_L16])
-        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*160
+        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*16
         e("s_mul_i32", T[3], [T[1], 4 * RING_SLOT])
         e("s_add_i32", T[3], [T[3], LDS_RING])
         e("s_add_i32", T[3], [T[3], S_LDSB])
-        e("v_mul_u32_u24", V_TMP, [160, V_LANE])
-        e("v_add_u32", V_RINGR, [T[3], V_TMP])
-        # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7, owner lane L = 32*(wv&1) + lane/2, pair = lane & 1;
+        e("v_add_u32", V_RINGR, [T[3], V_L16])
+        # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7, byte 4*xb = 512*(wv&1) + 8*lane inside a plane;
         # V_RINGW[x] serves gamma parity x ^ (wv & 1)
-        e("v_lshrrev_b32", V_TMP, [1, V_LANE])
-        e("s_lshl_b32", T[3], [T[1], 5])
+        e("v_lshlrev_b32", V_TMP, [3, V_LANE])
+        e("s_lshl_b32", T[3], [T[1], 9])
         e("v_add_u32", V_TMP, [T[3], V_TMP])
-        e("v_mul_u32_u24", V_TMP, [160, V_TMP])
-        e("v_and_b32", CK[0], [1, V_LANE])
-        e("v_lshlrev_b32", CK[0], [2, CK[0]])
-        e("v_add_u32", V_TMP, [V_TMP, CK[0]])
         for x in (0, 1):
             e("s_xor_b32", T[3], [T[1], x])            # gamma parity
             e("s_lshl_b32", T[3], [T[3], 2])
@@ -481,31 +538,44 @@ class Gen(object):
         e("s_lshl_b32", S_QB, [S_WV, 2])
         e("s_cmp_eq_u32", (), [S_WV, 7])
         e("s_cselect_b32", S_QB, [-4, S_QB])
-        # cooking pipeline: task n = row 4n - 1 + (wv>>1), half wv&1.  Task 0 is cooked synchronously, task 1 requested,
-        # the descriptor of task 2 fetched (both buffers: the first loop event reads either one, by wave parity)
-        e("s_add_i32", S_PQ, [T[2], -1])
-        self.desc_offset(T[0], S_PQ, 0)
-        e("s_load_dwordx8", CD[0], [S_PLAN, T[0]])
-        e("s_add_i32", S_PQ, [S_PQ, 4])
-        self.desc_offset(T[0], S_PQ, 0)
-        e("s_load_dwordx8", CD[1], [S_PLAN, T[0]])
+        # copy this workgroup's descriptor table to LDS: 512 threads x 16 bytes per sweep
+        e("s_lshl_b32", T[3], [S_WV, 10])
+        e("v_add_u32", V_TMP, [T[3], V_L16])              # tid * 16
+        e("s_add_i32", T[3], [S_LDSB, LDS_TAB])
+        e("v_add_u32", CK[4], [T[3], V_TMP])              # LDS destination
+        e("s_add_i32", S_TABB, [T[3], PADF * DESC_BYTES])
+        e("s_mov_b64", S(T[4].i, 2), [S_PLAN])
+        l_copied = self.p.newlabel("copied")
+        for i in range(TAB_MAX_ROWS // 512):
+            e("s_cmp_gt_u32", (), [S_NROWS, i * 512])
+            e("s_cbranch_scc0", (), [l_copied])
+            e("global_load_dwordx4", CK.sub(0, 4), [V_TMP, S(T[4].i, 2)])
+            e("s_add_u32", T[4], [T[4], 8192])
+            e("s_addc_u32", T[5], [T[5], 0])
+            self.p.waitcnt(vm=0)
+            e("ds_write_b128", (), [CK[4], CK.sub(0, 4)], offset=i * 8192)
+        self.p.label(l_copied)
         self.p.waitcnt(lgkm=0)
-        self.issue_task(CD[0])
-        e("s_barrier")                               # LDS zero-fill complete before anyone cooks into it
+        e("s_barrier")                               # LDS zero-fill and the table are complete
+        # cooking pipeline: task n = row 4n - 1 + (wv>>1), half wv&1.  Task 0 is cooked synchronously, task 1 requested.
+        e("s_lshr_b32", T[2], [S_WV, 1])
+        e("s_add_i32", S_PQ, [T[2], -1])
+        self.fetch_cook()
+        self.p.waitcnt(lgkm=0)
+        self.take_cook()
+        self.issue_task(S_CD)
+        e("s_add_i32", S_PQ, [S_PQ, 4])
+        self.fetch_cook()
         # gamma = 0 has parity 0: ring address V_RINGW[0 ^ (wv & 1)]
         e("s_and_b32", T[1], [S_WV, 1])
         e("s_cmp_eq_u32", (), [T[1], 0])
         e("s_cselect_b64", S(T[4].i, 2), [-1, 0])
         e("v_cndmask_b32", V_TMP, [V_RINGW[1], V_RINGW[0], S(T[4].i, 2)])
         self.cook_pending(V_TMP)
-        self.issue_task(CD[1])
+        self.p.waitcnt(lgkm=0)
+        self.take_cook()
+        self.issue_task(S_CD)
         e("s_add_i32", S_PQ, [S_PQ, 4])
-        self.desc_offset(T[0], S_PQ, 0)
-        e("s_load_dwordx8", CD[0], [S_PLAN, T[0]])
-        e("s_load_dwordx8", CD[1], [S_PLAN, T[0]])
-        # event descriptors for the waves that start inside their event window (wave 0: slot 0, wave 7: slot 3)
-        self.prefetch_event(0)
-        self.prefetch_event(3)
         self.p.waitcnt(lgkm=0)
         e("s_barrier")
         for w in range(NW):

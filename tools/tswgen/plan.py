@@ -4,7 +4,7 @@ Mirrors tools/tsw_model.py's planner except that the last band is shifted left t
 every band is 256 real columns wide."""
 import numpy as np
 
-from .kernel import PADF, PADB, F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED
+from .kernel import PADF, PADB, TAB_MAX_ROWS, F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED
 
 BW = 256
 
@@ -50,20 +50,30 @@ def stream_of(segs):
     return rows
 
 
-def max_stream(B, H, W, n_iter, n_wg):
+def stride_of(share, H, n_iter):
+    return PADF + share + (share // H + 2) * (2 * n_iter + 1) + PADB
+
+
+def plan_geo(B, H, W, n_iter, max_wg, min_rows=16):
+    """-> (n_wg, stride): as many workgroups as CUs, more when a share's table would not fit in LDS"""
     nb = len(plan_bands(W, n_iter))
     total = B * nb * H
-    share = -(-total // n_wg)
-    nseg = share // H + 2
-    return share + nseg * (2 * n_iter + 1)
+    n_wg = max(1, min(max_wg, total // min_rows))
+    while True:
+        share = -(-total // n_wg)
+        if stride_of(share, H, n_iter) <= TAB_MAX_ROWS:
+            return n_wg, stride_of(share, H, n_iter)
+        n_wg += max(1, n_wg // 8)
 
 
 def build_plan(B, H, W, n_iter, n_wg):
-    """-> (header int32[n_wg][4] = Q, last_step, 0, 0 ; table uint32[n_wg][stride][8])"""
+    """-> (header int32[n_wg][4] = Q, last_step, 0, 0 ; table uint32[n_wg][stride][4])"""
     bands = plan_bands(W, n_iter)
-    stride = PADF + max_stream(B, H, W, n_iter, n_wg) + PADB
+    total = B * len(bands) * H
+    stride = stride_of(-(-total // n_wg), H, n_iter)
+    assert stride <= TAB_MAX_ROWS
     hdr = np.zeros((n_wg, 4), np.int32)
-    tab = np.zeros((n_wg, stride, 8), np.uint32)
+    tab = np.zeros((n_wg, stride, 4), np.uint32)
     for g in range(n_wg):
         segs = share_segments(B, H, W, n_iter, bands, g, n_wg)
         rows = stream_of(segs)
@@ -85,9 +95,5 @@ def build_plan(B, H, W, n_iter, n_wg):
             d[0] = goff & 0xffffffff
             d[1] = goff >> 32
             d[2] = boff
-            d[3] = flags
-            d[4] = 0
-            d[5] = (lo - p0) | ((hi - p0) << 16)
-            d[6] = y
-            d[7] = p0
+            d[3] = flags | ((lo - p0) << 8) | ((hi - p0) << 20)
     return hdr, tab

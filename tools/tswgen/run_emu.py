@@ -40,7 +40,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             off[name] = 4096
             continue
         off[name] = cur
-        cur += al(arr.nbytes) + 4096
+        cur += al(arr.nbytes) + 4096 + (8192 if name == "plan" else 0)
     mem = np.zeros(cur + 4096, np.uint8)
     mem.view(np.float32)[:] = np.nan
     for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("plan", tab)):
@@ -63,7 +63,8 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             set64(K.S_HIN, off["hin"])
             set64(K.S_SP, off["sp"])
             set64(K.S_OUT, off["out"])
-            set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 32)
+            set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16)
+            w.s[K.S_NROWS.i] = tab.shape[1]
             w.s[K.S_W4.i] = 4 * W
             w.s[K.S_HW4.i] = 4 * H * W
             w.s[K.S_LAST.i] = int(hdr[wg, 1])
