@@ -108,6 +108,8 @@ class I(object):
 
     def is_fence(self):
         o = self.op
+        if o == "pseudo":
+            return False
         return (o in BRANCH or o in ("label", "s_waitcnt", "s_barrier", "s_nop", "s_endpgm", "raw") or
                 o == "s_and_saveexec_b64" or any(isinstance(d, R) and d.kind == "exec" for d in self.dst))
 
@@ -116,6 +118,8 @@ class I(object):
 
     # --- register sets (for the scheduler and the checks)
     def reads(self):
+        if self.op == "pseudo":
+            return list(self.mods["reads"])
         r = []
         for s in self.src:
             if isinstance(s, R):
@@ -130,6 +134,8 @@ class I(object):
         return r
 
     def writes(self):
+        if self.op == "pseudo":
+            return list(self.mods["writes"])
         w = []
         for d in self.dst:
             if isinstance(d, R):
@@ -146,6 +152,8 @@ class I(object):
         o, d, s, m = self.op, self.dst, self.src, self.mods
         if o == "label":
             return "%s:" % s[0]
+        if o == "pseudo":
+            return "\n".join(i.text() for i in m["expand"])
         if o == "raw":
             return s[0]
         if o == "s_waitcnt":
@@ -177,11 +185,15 @@ class I(object):
             t = "%s %s, %s, %s" % (o, optext(d[0]), optext(s[0]), optext(s[1]))
             if m.get("offset", 0):
                 t += " offset:%d" % m["offset"]
+            if m.get("cache"):
+                t += " " + m["cache"]
             return t
         if o in VMEM_ST:
             t = "%s %s, %s, %s" % (o, optext(s[0]), optext(s[1]), optext(s[2]))
             if m.get("offset", 0):
                 t += " offset:%d" % m["offset"]
+            if m.get("cache"):
+                t += " " + m["cache"]
             return t
         if o in SMEM:
             return "%s %s, %s, %s" % (o, optext(d[0]), optext(s[0]), optext(s[1]))
@@ -257,20 +269,26 @@ def _latency(prod, cons, reg):
     return 1
 
 
+SOFT_VALU_LATENCY = 1
+
+
 def schedule_region(region):
     """List-schedule a straight-line region (no fences inside).  Memory operations keep their relative order."""
     n = len(region)
     if n <= 1:
         return list(region)
     preds = [dict() for _ in range(n)]  # j -> min distance
+    soft = [dict() for _ in range(n)]   # j -> preferred distance (dependent VALU results are better not consumed next slot)
     last_write, readers = {}, {}
-    last_mem = None
+    last_mem = {}
     for j, ins in enumerate(region):
         rd, wr = ins.reads(), ins.writes()
         for r in rd:
             if r in last_write:
                 i = last_write[r]
                 preds[j][i] = max(preds[j].get(i, 0), _latency(region[i], ins, r))
+                if SOFT_VALU_LATENCY > 1 and r[0] == "v" and region[i].is_valu() and ins.is_valu():
+                    soft[j][i] = SOFT_VALU_LATENCY
         for r in wr:
             if r in last_write:
                 i = last_write[r]
@@ -280,10 +298,11 @@ def schedule_region(region):
                     lat = 2 if region[i].op in VMEM_ST and r[0] == "v" else 1  # store data: leave a gap before overwriting
                     # WAR: the reader must issue first (distance >= 1, same slot impossible anyway)
                     preds[j][i] = max(preds[j].get(i, 0), lat)
-        if ins.is_mem():
-            if last_mem is not None:
-                preds[j][last_mem] = max(preds[j].get(last_mem, 0), 1)
-            last_mem = j
+        if ins.is_mem():  # LDS and vector-memory operations each keep their own program order (separate counters)
+            ch = "ds" if ins.op in DS_OPS else "vm"
+            if last_mem.get(ch) is not None:
+                preds[j][last_mem[ch]] = max(preds[j].get(last_mem[ch], 0), 1)
+            last_mem[ch] = j
         for r in wr:
             last_write[r] = j
             readers[r] = []
@@ -305,8 +324,15 @@ def schedule_region(region):
         best = None
         for j in ready:
             ok = all(slot - slot_of[i] >= d for i, d in preds[j].items())
-            if ok and (best is None or (prio[j], -j) > (prio[best], -best)):
-                best = j
+            if not ok:
+                continue
+            # placement hint: an instruction nobody in the region waits for (publishing store, prefetch) is taken as soon
+            # as `at` (fraction of the region) has been issued; otherwise the critical path decides
+            at = region[j].mods.get("at")
+            relaxed = all(slot - slot_of[i] >= d for i, d in soft[j].items())
+            key = (1 if at is not None and slot >= at * n else 0, 1 if relaxed else 0, prio[j] if at is None else 0, -j)
+            if best is None or key > bestkey:
+                best, bestkey = j, key
         if best is None:
             out.append(I("s_nop", (), [0]))
             slot += 1
@@ -320,6 +346,17 @@ def schedule_region(region):
             if npred[j] == 0:
                 ready.append(j)
     return out
+
+
+def expand_pseudos(prog):
+    out = []
+    for ins in prog.ins:
+        if ins.op == "pseudo":
+            out += ins.mods["expand"]
+        else:
+            out.append(ins)
+    prog.ins = out
+    return prog
 
 
 def schedule(prog):

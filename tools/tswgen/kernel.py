@@ -12,7 +12,7 @@ Register / LDS maps are module constants; `build(cfg)` returns an isa.Prog.
 cfg: norm (0 '8sum', 1 '8sum_abs', 2 'none'), sparse (bool), hin (bool: level-0 values come from a previous pass),
 n_iter (only 24 for now).
 """
-from .isa import Prog, V, S, EXEC, schedule, check_hazards
+from .isa import Prog, V, S, EXEC, schedule, check_hazards, expand_pseudos
 
 NW, NSLOT, LV = 8, 4, 24
 PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
@@ -73,6 +73,7 @@ class Gen(object):
         self.p = Prog()
         self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
         assert cfg.get("n_iter", 24) == 24
+        self.stubs = []
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
 
     # ---------------------------------------------------------------------------------- small helpers
@@ -138,15 +139,15 @@ class Gen(object):
         """LDS reads of the descriptors the event of slot ev needs (issued with the boundary-row reads)"""
         self.desc_addr(T[0], S_QB, ev)
         self.mov(V_DE, T[0])
-        self.e("ds_read_b32", V_DE, [V_DE], offset=12)
+        self.e("ds_read_b32", V_DE, [V_DE], offset=12, at=0.0)
         self.e("s_add_i32", T[1], [T[0], -32 * DESC_BYTES])
         self.mov(V_DO[0], T[1])
-        self.e("ds_read_b64", V_DO, [V_DO[0]], offset=8)
+        self.e("ds_read_b64", V_DO, [V_DO[0]], offset=8, at=0.0)
 
     def fetch_cook(self):
         self.desc_addr(T[2], S_PQ, 0)
         self.mov(V_DC[0], T[2])
-        self.e("ds_read_b128", V_DC, [V_DC[0]])
+        self.e("ds_read_b128", V_DC, [V_DC[0]], at=0.0)
 
     def take_event(self):
         self.e("v_readfirstlane_b32", S_ENF, [V_DE])
@@ -176,13 +177,14 @@ class Gen(object):
         self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
         self.e("s_addc_u32", T[9], [S_OUT[1], 0])
         self.e("s_and_saveexec_b64", S(T[6].i, 2), [S(T[4].i, 2)])
-        self.e("global_store_dwordx4", (), [V_L16, OUTQ, S(T[8].i, 2)])
+        if "nostore" not in self.ab:
+            self.e("global_store_dwordx4", (), [V_L16, OUTQ, S(T[8].i, 2)], cache=self.cfg.get("st_cache"))
         self.e("s_mov_b64", EXEC, [S(T[6].i, 2)])
         self.p.label(lab)
 
     def inject(self, j, vq):
-        for k in range(9):
-            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 1024)
+        for k in self.late_planes(j):
+            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 1024, at=0.0)
         # the ring holds image order (c0,c1,c2,c3); registers hold (c0,c2,c1,c3)
         self.mov(vq[0], HN[0])
         self.mov(vq[3], HN[3])
@@ -195,52 +197,90 @@ class Gen(object):
         if j == 3:
             self.e("s_add_i32", S_QB, [S_QB, 32])
 
-    def act_check(self, j, vq):
-        lab = self.p.newlabel("act")
-        self.e("s_bitcmp1_b32", (), [S_ACT, j])
-        self.e("s_cbranch_scc1", (), [lab])
-        self.zero_quad(vq)
-        self.p.label(lab)
+    # event planes: the coefficient planes of slot j that are dead when the event step starts (the row in the slot only
+    # needs its below taps -- and, for slot 0, its above taps -- to finish its last level) can be replaced at the top of
+    # the step, together with the boundary-row reads; the others right after the row completed.  Nothing waits mid-step.
+    @staticmethod
+    def early_planes(j):
+        return (3, 4, 8) if j == 0 else (3, 4, 5, 6, 7, 8)
 
-    # ---------------------------------------------------------------------------------- one phase of the ring counter
+    @staticmethod
+    def late_planes(j):
+        return (0, 1, 2, 5, 6, 7) if j == 0 else (0, 1, 2)
+
+    def swap_planes(self, j, planes):
+        for k in planes:  # the ring holds image order (c0,c1,c2,c3); registers hold (c0,c2,c1,c3)
+            self.e("v_swap_b32", [WT(j, k)[1], WT(j, k)[2]], [WT(j, k)[2], WT(j, k)[1]])
+
+    def act_check(self, j, vq):
+        """a slot holding a separator / padding row is pinned to zero (0 x NaN from a neighbour must not leak into it).
+        Modelled as one pseudo instruction so that the scheduler may move independent work across it; the zeroing stub
+        lives out of line."""
+        stub, back = self.p.newlabel("actz"), self.p.newlabel("actb")
+        from .isa import I
+        exp = [I("s_bitcmp1_b32", (), [S_ACT, j]), I("s_cbranch_scc0", (), [stub]), I("label", (), [back])]
+        self.e("pseudo", (), (), expand=exp, reads=[("s", S_ACT.i)] + vq.regs(), writes=[("scc", 0)] + vq.regs())
+        self.stubs.append((stub, back, vq))
+
+    def tail(self, c, skip_above1=False):
+        """the part of step c nobody else waits for (slot 0's pushes after its value was published); emitted at the top of
+        the following step, between the boundary-row reads and their wait.  skip_above1: slot 1 is replaced in the
+        following step, the accumulator this push would start is re-initialised there"""
+        p = c & 1
+        v0 = ACC(p, 0)
+        self.shift(v0, TB)
+        self.push_self(0, v0, TB, ACC(p ^ 1, 0), init=WT(0, 8))
+        if not skip_above1:
+            self.push_above(1, v0, TB, ACC(p, 1), init=WT(1, 8))
+
     def step(self, c):
         p = c & 1
         N1 = [ACC(p, j) for j in range(4)]
         N2 = [ACC(p ^ 1, j) for j in range(4)]
         ev = c if c < 4 else None
+        pev = (c - 1) % LV if (c - 1) % LV < 4 else None   # the previous step's event slot: its late planes arrive now
         if "noevents" in self.ab:
-            ev = None
+            ev = pev = None
         cook = c % 3 == 2 and "nocook" not in self.ab
         self.p.label(".LS%d_%%=" % c)
+        # ---- top: everything that travels through LDS is requested first
+        if "nolds" not in self.ab:
+            self.e("ds_read_b128", BQ, [V_RB[p]], at=0.0)
+            self.e("ds_read_b128", TQ, [V_RT[p]], at=0.0)
         if ev is not None:
             self.fetch_event(ev)
+            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 1024, at=0.0)
+            if ev > 0:
+                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 1024, at=0.0)
+            if ev > 0:
+                for k in self.early_planes(ev):
+                    self.e("ds_read_b128", WT(ev, k), [V_RINGR], offset=ev * RING_SLOT + k * 1024, at=0.0)
         if cook:
             self.fetch_cook()
-        if ev is not None:
-            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 1024)
-            if ev > 0:
-                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 1024)
-        if "nolds" not in self.ab:
-            self.e("ds_read_b128", BQ, [V_RB[p]])
-            self.e("ds_read_b128", TQ, [V_RT[p]])
         loads = []
         if cook:
             # normalise + fold the pending task while the boundary rows arrive; its successor's inputs are requested
             # in small groups between the FMAs of this step (a burst of loads would stall every wave at once)
             g = ((c + 1) // 3) & 1
             self.cook_pending(V_RINGW[g])
+        self.tail((c - 1) % LV, skip_above1=(ev == 1))
+        if ev == 0:  # slot 0's self taps were still needed by the deferred tail
+            for k in self.early_planes(0):
+                self.e("ds_read_b128", WT(0, k), [V_RINGR], offset=k * 1024, at=0.0)
         self.p.waitcnt(lgkm=0)
+        if pev is not None:
+            self.swap_planes(pev, self.late_planes(pev))
         if ev is not None:
             self.take_event()
+            self.swap_planes(ev, self.early_planes(ev))
         if cook:
             self.take_cook()
             self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
             loads = self.load_list()
-        nl = len(loads)
-        cuts = [0, (nl + 4) // 5, (2 * nl + 4) // 5, (3 * nl + 4) // 5, (4 * nl + 4) // 5, nl]
+            for i, (dst, voff, base) in enumerate(loads):
+                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"), at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
         # received boundary rows
-        self.issue_loads(loads[cuts[0]:cuts[1]])
         self.shift(BQ, TA)
         self.push_below(3, BQ, TA, N1[3])
         self.shift(TQ, TB)
@@ -254,27 +294,21 @@ class Gen(object):
                 self.inject(j, vq)
             elif "noact" not in self.ab:
                 self.act_check(j, vq)
-            self.issue_loads(loads[cuts[4 - j]:cuts[5 - j]])
             if j == 3 and "nolds" not in self.ab:
-                self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024)
+                self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024, at=0.0)
             if j == 0 and "nolds" not in self.ab:
-                self.e("ds_write_b128", (), [V_WR[p], vq], offset=0)
+                self.e("ds_write_b128", (), [V_WR[p], vq], offset=0, at=0.0)
+            if j == 0:
+                break  # slot 0's own pushes: tail(), at the top of the next step
             self.shift(vq, tq)
-            if j > 0:
-                self.push_below(j - 1, vq, tq, N1[j - 1])
+            self.push_below(j - 1, vq, tq, N1[j - 1])
             if ev == j:
-                self.p.waitcnt(lgkm=0)  # the new coefficients
-                for k in range(9):
-                    self.e("v_swap_b32", [WT(j, k)[1], WT(j, k)[2]], [WT(j, k)[2], WT(j, k)[1]])
                 self.push_self(j, vq, tq, N2[j], init=WT(j, 8))
-                if j > 0:
-                    self.e("v_swap_b32", [HA[1], HA[2]], [HA[2], HA[1]])
-                    self.shift(HA, OUTQ)
-                    self.push_above(j, HA, OUTQ, N2[j])
-            elif j > 0:
-                self.push_self(j, vq, tq, N2[j])
+                self.e("v_swap_b32", [HA[1], HA[2]], [HA[2], HA[1]])
+                self.shift(HA, OUTQ)
+                self.push_above(j, HA, OUTQ, N2[j])
             else:
-                self.push_self(0, vq, tq, N2[0], init=WT(0, 8))
+                self.push_self(j, vq, tq, N2[j])
             if j < 3:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
         self.e("s_add_i32", S_TAU, [S_TAU, 1])
@@ -588,14 +622,23 @@ class Gen(object):
         for c in range(LV):
             self.step(c)
         self.p.label(".Lexit_%=")
+        self.e("s_branch", (), [".Lend_%="])
+        for stub, back, vq in self.stubs:
+            self.p.label(stub)
+            self.zero_quad(vq)
+            self.e("s_branch", (), [back])
+        self.p.label(".Lend_%=")
         return self.p
 
 
 def build(cfg, sched=True):
+    from . import isa
+    isa.SOFT_VALU_LATENCY = cfg.get("soft_lat", 1)
     g = Gen(cfg)
     p = g.build()
     if sched:
         schedule(p)
+    expand_pseudos(p)
     errs = check_hazards(p)
     if errs:
         raise RuntimeError("hazards:\n" + "\n".join(errs[:20]))
