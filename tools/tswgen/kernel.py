@@ -25,7 +25,7 @@ DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
 
 # flags in descriptor dword 3
-F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED = 0, 1, 2, 3, 4, 5
+F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED, F_PLAIN = 0, 1, 2, 3, 4, 5, 6  # PLAIN: active, interior row, interior band
 
 # ---- VGPR map ----
 V_LANE, V_COL4, V_L16 = V(0), V(1), V(2)
@@ -330,9 +330,14 @@ class Gen(object):
             self.p.waitcnt(vm=0)
         if "nocookmath" in self.ab:
             return
+        l_math = self.p.newlabel("cmath")
+        self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_PLAIN])   # most rows: nothing to patch
+        self.e("s_cbranch_scc1", (), [l_math])
         self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_ACTIVE])
         self.e("s_cbranch_scc0", (), [l_inact])
         if norm != 2:
+            # rows above / below the image were read from whatever lies there in the tensor (always inside it: the planes
+            # read at dy = -1 are channels 5..7, those at dy = +1 channels 0..2): they count as zero
             for flag, chans in ((F_UP, (0, 1, 2)), (F_DN, (5, 6, 7))):
                 lab = self.p.newlabel("edge")
                 self.e("s_bitcmp1_b32", (), [S_PFLAGS, flag])
@@ -344,12 +349,17 @@ class Gen(object):
             lab = self.p.newlabel("noedge")
             self.e("s_and_b32", T[0], [S_PFLAGS, (1 << F_FIRST) | (1 << F_LAST)])
             self.e("s_cbranch_scc0", (), [lab])
+            self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_FIRST])
+            self.e("s_cselect_b64", S_EL, [S_ELC, 0])
+            self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_LAST])
+            self.e("s_cselect_b64", S_ER, [S_ERC, 0])
             for k in range(8):
                 if DX[k] < 0:
                     self.e("v_cndmask_b32", g[k][0], [g[k][0], 0, S_EL])
                 if DX[k] > 0:
                     self.e("v_cndmask_b32", g[k][1], [g[k][1], 0, S_ER])
             self.p.label(lab)
+        self.p.label(l_math)
         # temporaries
         # (the boundary rows are arriving in TQ / BQ / HN / HA: only TA, TB and OUTQ are free here)
         sx, sy = TA[0], TA[1]
@@ -422,28 +432,12 @@ class Gen(object):
         self.p.label(l_done)
 
     def issue_prepare(self, cd):
-        """scalar side of a task request: flags, edge-lane masks and the base addresses of its rows (kept in s0..s11 so that
-        the loads themselves can be spread over the following step)"""
+        """scalar side of a task request: flags and the base addresses of its rows (kept in s0..s11 while the loads are
+        issued between the FMAs of the step).  No clamping: a row above / below the image, or the all-zero descriptor of
+        an inactive row, still addresses memory inside the tensors (see cook_pending)."""
         self.e("s_mov_b32", S_PFLAGS, [cd[3]])
-        self.e("s_bitcmp1_b32", (), [cd[3], F_FIRST])
-        self.e("s_cselect_b64", S_EL, [S_ELC, 0])
-        self.e("s_bitcmp1_b32", (), [cd[3], F_LAST])
-        self.e("s_cselect_b64", S_ER, [S_ERC, 0])
         self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[0]])
         self.e("s_addc_u32", GB_MID[1], [S_GD[1], cd[1]])
-        if self.norm != 2:
-            # row below / above outside the image: read this row instead (zeroed when cooked).  An inactive row has an
-            # all-zero descriptor: it loads (and ignores) the first rows of the tensors, so it must not be clamped.
-            self.e("s_bitcmp1_b32", (), [cd[3], F_ACTIVE])
-            self.e("s_cselect_b32", T[6], [cd[3], (1 << F_UP) | (1 << F_DN)])
-            self.e("s_bitcmp1_b32", (), [T[6], F_UP])
-            self.e("s_cselect_b32", T[7], [0, S_W4])
-            self.e("s_sub_u32", GB_UP[0], [GB_MID[0], T[7]])
-            self.e("s_subb_u32", GB_UP[1], [GB_MID[1], 0])
-            self.e("s_bitcmp1_b32", (), [T[6], F_DN])
-            self.e("s_cselect_b32", T[7], [0, S_W4])
-            self.e("s_add_u32", GB_DN[0], [GB_MID[0], T[7]])
-            self.e("s_addc_u32", GB_DN[1], [GB_MID[1], 0])
         self.e("s_add_u32", B_BLUR[0], [S_BLUR[0], cd[2]])
         self.e("s_addc_u32", B_BLUR[1], [S_BLUR[1], 0])
         if self.hin:
@@ -456,7 +450,7 @@ class Gen(object):
     def load_list(self):
         if "nocookload" in self.ab:
             return []
-        bases = [GB_MID] * 8 if self.norm == 2 else [GB_UP, GB_UP, GB_UP, GB_MID, GB_MID, GB_DN, GB_DN, GB_DN]
+        bases = [GB_MID] * 8
         items = [(PEND_G[k], V_OFFK[k], bases[k]) for k in range(8)]
         if "alignedloads" in self.ab:
             items = [(PEND_G[k], V_OFF1, bases[k]) for k in range(8)]
@@ -559,7 +553,7 @@ class Gen(object):
                     e("s_add_i32", T[3], [T[3], S_W4])
                 if DY[k] < 0:
                     e("s_sub_i32", T[3], [T[3], S_W4])
-                if DX[k] != 0:
+                if DX[k] != 0 and "aligned2" not in self.ab:
                     e("s_add_i32", T[3], [T[3], 4 * DX[k]])
             e("v_add_u32", V_OFFK[k], [T[3], V_OFF1])
         # constant edge-lane masks

@@ -4,7 +4,7 @@ Mirrors tools/tsw_model.py's planner except that the last band is shifted left t
 every band is 256 real columns wide."""
 import numpy as np
 
-from .kernel import PADF, PADB, TAB_MAX_ROWS, F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED
+from .kernel import PADF, PADB, TAB_MAX_ROWS, F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED, F_PLAIN
 
 BW = 256
 
@@ -29,13 +29,19 @@ def plan_bands(W, n_iter):
 
 
 def share_segments(B, H, W, n_iter, bands, g, n_wg):
-    total = B * len(bands) * H
-    r0, r1 = g * total // n_wg, (g + 1) * total // n_wg
+    """Workgroup g = nb * G + band: group G owns a contiguous range of the B*H image rows, its nb workgroups take one band
+    each, so the workgroups that read overlapping columns of the same rows run side by side (their halo re-reads hit in
+    cache instead of HBM)."""
+    nb = len(bands)
+    assert n_wg % nb == 0
+    ng = n_wg // nb
+    G, bi = divmod(g, nb)
+    total = B * H
+    r0, r1 = G * total // ng, (G + 1) * total // ng
     segs, r = [], r0
     while r < r1:
-        u, y0 = divmod(r, H)
+        b, y0 = divmod(r, H)
         y1 = min(H, y0 + (r1 - r))
-        b, bi = divmod(u, len(bands))
         segs.append((b, bi, max(0, y0 - n_iter), min(H, y1 + n_iter), y0, y1))
         r += y1 - y0
     return segs
@@ -55,22 +61,23 @@ def stride_of(share, H, n_iter):
 
 
 def plan_geo(B, H, W, n_iter, max_wg, min_rows=16):
-    """-> (n_wg, stride): as many workgroups as CUs, more when a share's table would not fit in LDS"""
+    """-> (n_wg, stride): groups of nb workgroups; as many groups as fit on the CUs, more when a share's table would not
+    fit in LDS"""
     nb = len(plan_bands(W, n_iter))
-    total = B * nb * H
-    n_wg = max(1, min(max_wg, total // min_rows))
+    total = B * H
+    ng = max(1, min(max_wg // nb, total // min_rows))
     while True:
-        share = -(-total // n_wg)
+        share = -(-total // ng)
         if stride_of(share, H, n_iter) <= TAB_MAX_ROWS:
-            return n_wg, stride_of(share, H, n_iter)
-        n_wg += max(1, n_wg // 8)
+            return ng * nb, stride_of(share, H, n_iter)
+        ng += max(1, ng // 8)
 
 
 def build_plan(B, H, W, n_iter, n_wg):
     """-> (header int32[n_wg][4] = Q, last_step, 0, 0 ; table uint32[n_wg][stride][4])"""
     bands = plan_bands(W, n_iter)
-    total = B * len(bands) * H
-    stride = stride_of(-(-total // n_wg), H, n_iter)
+    assert n_wg % len(bands) == 0
+    stride = stride_of(-(-(B * H) // (n_wg // len(bands))), H, n_iter)
     assert stride <= TAB_MAX_ROWS
     hdr = np.zeros((n_wg, 4), np.int32)
     tab = np.zeros((n_wg, stride, 4), np.uint32)
@@ -91,6 +98,8 @@ def build_plan(B, H, W, n_iter, n_wg):
             boff = 4 * (b * H * W + y * W + p0)
             flags = (1 << F_ACTIVE) | ((y + 1 < H) << F_UP) | ((y >= 1) << F_DN) | ((p0 == 0) << F_FIRST) | \
                     ((p0 + BW == W) << F_LAST) | ((y0 <= y < y1) << F_OWNED)
+            if 1 <= y < H - 1 and p0 > 0 and p0 + BW < W:
+                flags |= 1 << F_PLAIN
             d = tab[g, PADF + q]
             d[0] = goff & 0xffffffff
             d[1] = goff >> 32

@@ -30,6 +30,9 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
     prog = K.build(dict(norm=norm, sparse=sparse, hin=hin), sched=sched)
+    from .plan import plan_bands
+    nb = len(plan_bands(W, n_iter))
+    n_wg = -(-n_wg // nb) * nb   # whole groups of nb workgroups
     hdr, tab = build_plan(B, H, W, n_iter, n_wg)
     # global memory image
     def al(n):
