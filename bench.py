@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS) + ["vol3d"])
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
@@ -88,6 +88,83 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
     }
 
 
+def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
+    """BASELINE config 5: 3x3x3 propagation, 12 iterations, 32x160x608 volume, batch 4 per GPU, gates normalised by the
+    caller and used as given (the fluid.layers.affinity_propagate contract, reference cspn_paddle/demo.py:41-52): one
+    step3d_direct_kernel launch per iteration, each moving exactly the algorithmic bytes of a single step."""
+    B, D, H, W, n_iter = (4 if a.batch_per_gpu == 64 else a.batch_per_gpu), 32, 160, 608, 12
+    gen = torch.Generator(device=dev).manual_seed(5000 + rank)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=dev)
+    g /= g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device=dev)
+    out = torch.empty_like(h)
+    ws_bytes = lib.cspn3d_workspace_bytes(B, D, H, W, n_iter)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    norm = _lib.NORM_TYPES["none"]
+
+    def step():
+        _lib.check(lib.cspn3d_forward_f32(g.data_ptr(), h.data_ptr(), None, out.data_ptr(), B, D, H, W, n_iter, norm,
+                                          ws.data_ptr(), ws_bytes, stream.cuda_stream), "cspn3d_forward_f32")
+
+    steps, warmup = min(a.steps, 60), min(a.warmup, 20)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms_avg = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
+    if dist is not None:
+        t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms_avg = float(t[0]), float(t[1])
+    if rank == 0:
+        vox = B * D * H * W
+        launch_ms = dev_ms_avg / n_iter            # n_iter identical launches per forward, nothing else on the stream
+        achieved = vox * 112 / (launch_ms * 1e-3) / 1e9
+        res = {
+            "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
+            "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (uniform gates normalised over the 26 channels, uniform feature volume; generated on device)",
+            "config": {"workload": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 volume, batch %d per GPU" % B,
+                       "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none (gates pre-normalised by the caller)",
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
+                         "whole_forward_frac": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "per launch = one propagation step (26 gates + value in, value out = 112 B/voxel); "
+                                 "whole_forward_frac prices all 12 iterations against a single pass over the inputs"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import cspn3d_oracle, oracle_threads, set_oracle_threads
+            set_oracle_threads(min(os.cpu_count() or 1, 64))
+            gc, hc = g[:, :, :, :40].cpu(), h[:, :, :, :40].cpu()   # bounded sample: a 32x40x608 slab of every volume
+            cspn3d_oracle(gc[:1], hc[:1], None, 1, "none")
+            t0 = time.perf_counter()
+            cspn3d_oracle(gc, hc, None, n_iter, "none")
+            dt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": round(gc.shape[0] * D * 40 * W * n_iter / 1e6 / dt, 2), "unit": "Mvox*iters/s",
+                                   "cores": oracle_threads(), "kind": "port",
+                                   "sample": "%d volumes 32x40x608 x %d iters, oracle/cspn_oracle.c (OpenMP over volumes)" % (gc.shape[0], n_iter)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +204,8 @@ def main():
             broadcast_ms = (time.perf_counter() - t0) * 1e3
             del buf
 
+    if a.workload == "vol3d":
+        return run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu)
     H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
     B = a.batch_per_gpu
     g, h, s = synth(B, H, W, scale, sparse, dev, 1000 + rank)

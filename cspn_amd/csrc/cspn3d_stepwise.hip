@@ -83,6 +83,63 @@ __global__ __launch_bounds__(256) void step3d_kernel(const float* __restrict__ w
     hout[idx] = acc;
 }
 
+// The Paddle contract (norm_type NONE, no sparse): gates are used as given, centre-sited, no centre term
+// (reference cspn_paddle/README.md:54-56, demo.py:41-52).  One iteration then needs exactly the algorithmic traffic of a
+// single propagation step -- 26 gates + value in, value out = 112 B/voxel -- so it reads the gate tensor directly: no
+// fold pass, no coefficient planes.  4 voxels per thread along x (16-byte loads of the gate planes).
+__global__ __launch_bounds__(256) void step3d_direct_kernel(const float* __restrict__ g, const float* __restrict__ hin,
+                                                             float* __restrict__ hout, int B, int D, int H, int W4) {
+    const int W = 4 * W4;
+    const size_t HW = (size_t)H * W, V = (size_t)D * HW, total4 = (size_t)B * D * H * W4;
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= total4) return;
+    const size_t idx = 4 * i4;
+    const int b = (int)(idx / V);
+    const size_t r = idx - (size_t)b * V;
+    const int z = (int)(r / HW);
+    const int r2 = (int)(r - (size_t)z * HW);
+    const int y = r2 / W, x = r2 - y * W;
+    const float* hb = hin + (size_t)b * V;
+    const float* gb = g + (size_t)b * 26 * V + r;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {  // the 9 neighbour rows (dz, dy); three x-taps each
+        const int dz = 1 - n / 3, dy = 1 - n % 3;
+        const int zz = z + dz, yy = y + dy;
+        float hm = 0.f, hp = 0.f;
+        float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (zz >= 0 && zz < D && yy >= 0 && yy < H) {
+            const float* row = hb + ((size_t)zz * H + yy) * W;
+            hc = *reinterpret_cast<const float4*>(row + x);
+            if (x > 0) hm = row[x - 1];
+            if (x + 4 < W) hp = row[x + 4];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {  // dx = 1 - t
+            const int c27 = n * 3 + t;   // raster index (f,t,l) with f = n/3, t = n%3, l = t
+            if (c27 == 13) continue;     // the centre has no gate
+            const int k = c27 < 13 ? c27 : c27 - 1;
+            const float4 w = *reinterpret_cast<const float4*>(gb + (size_t)k * V);
+            const int dx = 1 - t;
+            const float h0 = dx > 0 ? hc.y : (dx < 0 ? hm : hc.x);
+            const float h1 = dx > 0 ? hc.z : (dx < 0 ? hc.x : hc.y);
+            const float h2 = dx > 0 ? hc.w : (dx < 0 ? hc.y : hc.z);
+            const float h3 = dx > 0 ? hp : (dx < 0 ? hc.z : hc.w);
+            acc.x = fmaf(w.x, h0, acc.x);
+            acc.y = fmaf(w.y, h1, acc.y);
+            acc.z = fmaf(w.z, h2, acc.z);
+            acc.w = fmaf(w.w, h3, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(hout + idx) = acc;
+}
+
+static bool direct3d_ok(const float* g, const float* feat, const float* sparse, const float* out, int W, int norm,
+                        const void* ws) {
+    return norm == CSPN_NORM_NONE && sparse == nullptr && (W % 4) == 0 &&
+           (((uintptr_t)g | (uintptr_t)feat | (uintptr_t)out | (uintptr_t)ws) & 15u) == 0;
+}
+
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter) {
     (void)n_iter;
     return (27 + 2) * (size_t)B * D * H * W * sizeof(float);
@@ -92,6 +149,17 @@ int stepwise3d_forward(const float* g, const float* feat, const float* sparse, f
                        int W, int n_iter, int norm, void* ws, hipStream_t st) {
     const size_t total = (size_t)B * D * H * W;
     float* wf = (float*)ws;
+    if (direct3d_ok(g, feat, sparse, out, W, norm, ws)) {
+        float* pp[2] = {wf, wf + total};
+        const unsigned blocks4 = (unsigned)((total / 4 + 255) / 256);
+        const float* src = feat;
+        for (int it = 0; it < n_iter; ++it) {
+            float* dst = (it == n_iter - 1) ? out : pp[it & 1];
+            hipLaunchKernelGGL(step3d_direct_kernel, dim3(blocks4), dim3(256), 0, st, g, src, dst, B, D, H, W / 4);
+            src = dst;
+        }
+        return check_launch("step3d_direct_kernel");
+    }
     float* ping[2] = {wf + 27 * total, wf + 28 * total};
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(fold3d_kernel, dim3(blocks), dim3(256), 0, st, g, feat, sparse, wf, B, D, H, W, norm);

@@ -167,7 +167,10 @@ def test_full_size_configs(name, B, H, W, scale, sparse):
 # ---- 3D ----
 
 @pytest.mark.parametrize("B,D,H,W,N,norm,sp", [(1, 4, 9, 11, 5, "8sum_abs", False), (2, 6, 10, 37, 12, "8sum", True),
-                                               (1, 3, 8, 64, 3, "none", False), (1, 1, 1, 1, 2, "8sum", False)])
+                                               (1, 3, 8, 64, 3, "none", False), (1, 1, 1, 1, 2, "8sum", False),
+                                               (2, 5, 7, 12, 12, "none", False),   # direct kernel, ping-pong over 12 launches
+                                               (1, 2, 5, 10, 2, "none", False),    # W % 4 != 0: general path
+                                               (1, 4, 6, 16, 3, "none", True)])    # sparse pins: general path
 def test_3d_parity_vs_oracle(B, D, H, W, N, norm, sp):
     gen = torch.Generator().manual_seed(D * 100 + H)
     g = torch.randn(B, 26, D, H, W, generator=gen) if norm == "8sum" else torch.rand(B, 26, D, H, W, generator=gen)
@@ -199,6 +202,16 @@ def test_3d_config5_shape_properties():
     gc, hc = g[:1, :, :6, :24, :40].contiguous(), h[:1, :, :6, :24, :40].contiguous()
     oc = cspn_amd.cspn3d_forward(gc, hc, None, 12, "8sum_abs")
     assert rel_err(oc.cpu().numpy(), cspn3d_oracle(gc.cpu(), hc.cpu(), None, 12, "8sum_abs")) <= RTOL
+    # the Paddle contract at full size (gates normalised by the caller, used as given): direct one-pass-per-step kernel
+    gn = g / g.sum(1, keepdim=True)
+    on = cspn_amd.cspn3d_forward(gn, h, None, 12, "none")
+    assert float(on.min()) >= -1e-5 and float(on.max()) <= 1.0 + 1e-5
+    # no centre term in this mode: mass leaks through the zero border, 12 voxels deep; the interior keeps a constant
+    oc = cspn_amd.cspn3d_forward(gn, const, None, 12, "none")[:, :, 12:-12, 12:-12, 12:-12]
+    assert float((oc - 3.0).abs().max()) <= 3.0 * RTOL
+    gc = gn[1:2, :, :6, :24, :40].contiguous()
+    oc = cspn_amd.cspn3d_forward(gc, hc, None, 12, "none")
+    assert rel_err(oc.cpu().numpy(), cspn3d_oracle(gc.cpu(), hc.cpu(), None, 12, "none")) <= RTOL
 
 
 def test_paddle_style_affinity_propagate():
