@@ -38,3 +38,50 @@ def test_generated_include_is_current_and_hazard_free():
         p = K.build(dict(norm=norm, sparse=bool(sparse), hin=bool(hin)))
         assert not check_hazards(p)
         assert ("#define TSW_ASM_%d_%d_%d R\"ASM(\n%s\n)ASM\"" % (norm, sparse, hin, p.text())) in inc
+
+
+def test_scheduler_respects_hazards_and_emulator_flags_misuse():
+    """the tooling the generated loop relies on: VALU->DPP distance, waitcnt tracking, LDS race detection"""
+    from tools.tswgen.isa import Prog, V, S, schedule
+    from tools.tswgen.emu import Emu, EmuError
+    # 1. a DPP read right behind the VALU write of its source is separated by the scheduler (or s_nop) and accepted
+    p = Prog()
+    p.emit("v_mov_b32", V(1), [1.0])
+    p.emit("v_mov_b32", V(2), V(1), dpp="wave_shr:1")
+    p.emit("v_mov_b32", V(3), [2.0])
+    assert check_hazards(p), "unscheduled: must be reported"
+    schedule(p)
+    assert not check_hazards(p)
+    # 2. reading a register whose LDS load has not been waited for is an emulator error
+    p = Prog()
+    p.emit("v_mov_b32", V(1), [0])
+    p.emit("ds_read_b32", V(2), [V(1)])
+    p.emit("v_mov_b32", V(3), V(2))
+    with pytest.raises(EmuError, match="outstanding"):
+        Emu(p, np.zeros(8192, np.uint8), 1024, nwaves=1).run()
+    # 3. two waves touching the same LDS dword inside one barrier epoch is a race; across a barrier it is not
+    for with_barrier in (False, True):
+        p = Prog()
+        p.emit("v_mov_b32", V(1), [0])
+        p.emit("s_cmp_eq_u32", (), [S(31), 0])
+        p.emit("s_cbranch_scc0", (), [".Lreader"])
+        p.emit("ds_write_b32", (), [V(1), V(1)])
+        p.waitcnt(lgkm=0)
+        p.emit("s_barrier")
+        p.emit("s_branch", (), [".Lend"])
+        p.label(".Lreader")
+        if with_barrier:
+            p.emit("s_barrier")
+        p.emit("ds_read_b32", V(2), [V(1)])
+        p.waitcnt(lgkm=0)
+        if not with_barrier:
+            p.emit("s_barrier")
+        p.label(".Lend")
+        e = Emu(p, np.zeros(8192, np.uint8), 1024, nwaves=2)
+        for w in e.waves:
+            w.s[31] = w.wid
+        if with_barrier:
+            e.run()
+        else:
+            with pytest.raises(EmuError, match="race"):
+                e.run()
