@@ -52,6 +52,10 @@ def load():
     lib.cspn2d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp, c_size_t, vp]
     lib.cspn2d_forward_f32_algo.restype = c_int
     lib.cspn2d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    lib.cspn2d_backward_workspace_bytes.restype = c_size_t
+    lib.cspn2d_backward_workspace_bytes.argtypes = [c_int] * 4
+    lib.cspn2d_backward_f32.restype = c_int
+    lib.cspn2d_backward_f32.argtypes = [vp] * 6 + [c_int] * 5 + [vp, c_size_t, vp]
     lib.cspn3d_workspace_bytes.restype = c_size_t
     lib.cspn3d_workspace_bytes.argtypes = [c_int] * 5
     lib.cspn3d_forward_f32.restype = c_int

@@ -13,7 +13,9 @@ Differences a caller can observe, all deliberate:
     during its first forward, cspn.py:44-53; checkpoints are key-filtered on load,
     update_model.py:16-23, so both directions keep working);
   * inputs must already be on the GPU (the reference calls .cuda() itself, cspn.py:50);
-  * forward only: autograd through the op raises until the backward kernels land."""
+  * differentiable w.r.t. guidance and blur_depth (HIP backward kernels, cspn_amd/csrc/cspn2d_backward.hip: the gradient
+    torch autograd computes through the reference forward, which reference train.py:196-198 back-propagates through);
+    sparse_depth gets no gradient (only its sign is used, cspn.py:64)."""
 import torch
 import torch.nn as nn
 
@@ -23,13 +25,16 @@ from . import functional as F
 class _CSPN2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, guidance, blur_depth, sparse_depth, n_iter, norm_type, algo):
+        ctx.save_for_backward(guidance, blur_depth, sparse_depth)
+        ctx.n_iter, ctx.norm_type = n_iter, norm_type
         return F.cspn2d_forward(guidance, blur_depth, sparse_depth, n_iter, norm_type, algo)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "cspn_amd.Affinity_Propagate: backward is not implemented yet (forward-only engine); "
-            "run under torch.no_grad() / detach the inputs")
+        guidance, blur_depth, sparse_depth = ctx.saved_tensors
+        gg, gh = F.cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, ctx.n_iter, ctx.norm_type,
+                                   need_guidance=ctx.needs_input_grad[0], need_blur=ctx.needs_input_grad[1])
+        return gg, gh, None, None, None, None
 
 
 class Affinity_Propagate(nn.Module):

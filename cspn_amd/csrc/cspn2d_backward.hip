@@ -1,0 +1,153 @@
+// cspn2d_backward.hip -- gradient of Affinity_Propagate.forward (reference cspn_pytorch/models/cspn.py:42-83) with respect
+// to guidance and blur_depth: what torch autograd computes when reference train.py:196-198 back-propagates through the
+// module.  First version: correct and coalesced, one launch per iteration; not yet fused.
+//
+// Forward, folded (cspn2d_stepwise.hip):  H_{t+1} = c' + sum_k w'_k * shift_k(H_t),  w'_k = (1-m) w_k,
+//   c' = (1-m)(1-sigma) H_0 + m H_0,  w_k = G_k / S,  S = sum_j |G_j|,  G_k(p) = g~_k(p + off_k),  sigma = sum_k w_k.
+// Adjoint:  A_N = dL/dout,   A_t(p) = sum_k (w'_k A_{t+1})(p - off_k)          (bwd_step_kernel, N launches)
+//           dW'_k(p) = sum_t A_{t+1}(p) H_t(p + off_k),   dC(p) = sum_t A_{t+1}(p)   (bwd_final_kernel, from the two histories)
+//           dL/dw_k = (1-m)(dW'_k - dC H_0);   dL/dH_0 = A_0 + dC ((1-m)(1-sigma) + m)
+//           dL/dG_k = dL/dw_k / S - sign(G_k) (sum_j dL/dw_j G_j) / S^2          (torch: d|x|/dx = sign(x), 0 at 0)
+//           dL/dg_k(p + off_k) = dL/dG_k(p)  [* sign(g) for '8sum_abs'];  elements no pixel reads get 0.
+// The H_t history is recomputed here with the stepwise kernels (the fused forward keeps nothing).
+#include "cspn_common.h"
+
+namespace cspn {
+
+// from cspn2d_stepwise.hip
+__global__ void fold2d_kernel(const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse,
+                              float* __restrict__ wf, int B, int H, int W, int norm);
+__global__ void step2d_kernel(const float* __restrict__ wf, const float* __restrict__ hin, float* __restrict__ hout, int B,
+                              int H, int W);
+
+namespace {
+
+// A_t(p) = sum_k w'_k(q) A_{t+1}(q),  q = p - off_k inside the image
+__global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__ wf, const float* __restrict__ ain,
+                                                        float* __restrict__ aout, int B, int H, int W) {
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = (int)(idx / HW);
+    const int r = (int)(idx - (size_t)b * HW);
+    const int y = r / W, x = r - y * W;
+    const size_t base = (size_t)b * HW;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int yy = y - dy2(k), xx = x - dx2(k);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const size_t q = base + (size_t)yy * W + xx;
+            acc = fmaf(wf[k * total + q], ain[q], acc);
+        }
+    }
+    aout[idx] = acc;
+}
+
+// hh: H_1 .. H_{N-1} (H_0 = blur); ah: A_0 .. A_{N-1} (A_N = grad_out)
+__global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict__ g, const float* __restrict__ blur,
+                                                         const float* __restrict__ sparse, const float* __restrict__ hh,
+                                                         const float* __restrict__ ah, const float* __restrict__ gout,
+                                                         float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W,
+                                                         int n_iter, int norm) {
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = (int)(idx / HW);
+    const int r = (int)(idx - (size_t)b * HW);
+    const int y = r / W, x = r - y * W;
+    const size_t base = (size_t)b * HW;
+    int noff[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int yy = y + dy2(k), xx = x + dx2(k);
+        ok[k] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        noff[k] = ok[k] ? yy * W + xx : r;
+    }
+    float dW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dC = 0.f;
+    for (int t = 0; t < n_iter; ++t) {
+        const float a = (t + 1 == n_iter) ? gout[idx] : ah[(size_t)(t + 1) * total + idx];
+        const float* ht = (t == 0) ? blur : hh + (size_t)(t - 1) * total;
+        dC += a;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dW[k] = fmaf(a, ok[k] ? ht[base + noff[k]] : 0.f, dW[k]);
+    }
+    const float h0 = blur[idx];
+    const float m = sparse ? signf(sparse[idx]) : 0.f;
+    const float om = 1.f - m;
+    const float a0 = ah[idx];
+    const float* gbp = g + (size_t)b * 8 * HW;
+    if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
+        if (gb) gb[idx] = a0 + dC * m;
+        if (gg) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gg[(size_t)b * 8 * HW + k * HW + r] = om * dW[k];
+        }
+        return;
+    }
+    float G[8], S = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = ok[k] ? gbp[k * HW + noff[k]] : 0.f;
+        if (norm == CSPN_NORM_8SUM_ABS) v = fabsf(v);
+        G[k] = v;
+        S += fabsf(v);
+    }
+    float sigma = 0.f, T1 = 0.f, dw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sigma += G[k] / S;
+        dw[k] = om * (dW[k] - dC * h0);
+        T1 = fmaf(dw[k], G[k], T1);
+    }
+    if (gb) gb[idx] = a0 + dC * (om * (1.f - sigma) + m);
+    if (gg) {
+        const float t2 = T1 / (S * S);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!ok[k]) continue;  // the zero padding is a constant
+            const float sg = G[k] > 0.f ? 1.f : (G[k] < 0.f ? -1.f : 0.f);
+            float d = dw[k] / S - sg * t2;
+            if (norm == CSPN_NORM_8SUM_ABS) {
+                const float raw = gbp[k * HW + noff[k]];
+                d *= raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+            }
+            gg[(size_t)b * 8 * HW + k * HW + noff[k]] = d;  // g_k(p + off_k) is read by pixel p only
+        }
+    }
+}
+
+}  // namespace
+
+size_t backward2d_workspace(int B, int H, int W, int n_iter) {
+    const size_t total = (size_t)B * H * W;
+    return (size_t)(9 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
+}
+
+int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
+               int W, int n_iter, int norm, void* ws, hipStream_t st) {
+    const size_t total = (size_t)B * H * W;
+    float* wf = (float*)ws;
+    float* hh = wf + 9 * total;                       // H_1 .. H_{N-1}
+    float* ah = hh + (size_t)(n_iter - 1) * total;    // A_0 .. A_{N-1}
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(fold2d_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, wf, B, H, W, norm);
+    if (int e = check_launch("fold2d_kernel")) return e;
+    for (int t = 1; t < n_iter; ++t)
+        hipLaunchKernelGGL(step2d_kernel, dim3(blocks), dim3(256), 0, st, wf, t == 1 ? blur : hh + (size_t)(t - 2) * total,
+                           hh + (size_t)(t - 1) * total, B, H, W);
+    for (int t = n_iter - 1; t >= 0; --t)
+        hipLaunchKernelGGL(bwd_step_kernel, dim3(blocks), dim3(256), 0, st, wf,
+                           t == n_iter - 1 ? gout : ah + (size_t)(t + 1) * total, ah + (size_t)t * total, B, H, W);
+    if (int e = check_launch("bwd_step_kernel")) return e;
+    if (gg && norm != CSPN_NORM_NONE) {
+        hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipLaunchKernelGGL(bwd_final_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, gout, gg, gb, B, H, W, n_iter,
+                       norm);
+    return check_launch("bwd_final_kernel");
+}
+
+}  // namespace cspn

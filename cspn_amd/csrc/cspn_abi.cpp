@@ -93,6 +93,24 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
                                    ws_bytes, stream);
 }
 
+size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter) {
+    if (B <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    return backward2d_workspace(B, H, W, n_iter);
+}
+
+int cspn2d_backward_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
+                        float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type, void* ws,
+                        size_t ws_bytes, cspn_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d H=%d W=%d", B, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if (n_iter < 1) { set_error("backward needs n_iter >= 1 (got %d)", n_iter); return CSPN_E_BADARG; }
+    if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
+    if (!grad_out) { set_error("null grad_out"); return CSPN_E_BADARG; }
+    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_workspace(B, H, W, n_iter))) return e;
+    if (!grad_guidance && !grad_blur) return 0;
+    return backward2d(guidance, blur, sparse, grad_out, grad_guidance, grad_blur, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream);
+}
+
 size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     return stepwise3d_workspace(B, D, H, W, n_iter);

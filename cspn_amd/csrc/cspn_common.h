@@ -45,4 +45,9 @@ int tsw2d_build_plan(int B, int H, int W, void* plan_ws, hipStream_t st);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
                int W, int norm, const void* plan_ws, hipStream_t st);
 
+// ---- backward of the 2D op (cspn2d_backward.hip) ----
+size_t backward2d_workspace(int B, int H, int W, int n_iter);
+int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
+               int W, int n_iter, int norm, void* ws, hipStream_t st);
+
 }  // namespace cspn

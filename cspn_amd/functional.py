@@ -52,6 +52,32 @@ def cspn2d_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type
     return out
 
 
+def cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, norm_type="8sum",
+                    need_guidance=True, need_blur=True):
+    """Gradient of cspn2d_forward w.r.t. guidance and blur_depth (what autograd computes through reference
+    cspn_pytorch/models/cspn.py:42-83, back-propagated by reference train.py:196-198) in the HIP engine.
+    -> (grad_guidance [B,8,H,W] or None, grad_blur [B,1,H,W] or None)"""
+    lib = _lib.load()
+    B, _, H, W = guidance.shape
+    g = _prep(guidance, "guidance", (B, 8, H, W))
+    h = _prep(blur_depth, "blur_depth", (B, 1, H, W))
+    s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
+    go = _prep(grad_out, "grad_out", (B, 1, H, W))
+    gg = torch.empty_like(g) if need_guidance else None
+    gh = torch.empty_like(h) if need_blur else None
+    if B == 0 or not (need_guidance or need_blur):
+        return gg, gh
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn2d_backward_workspace_bytes(B, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        rc = lib.cspn2d_backward_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, go.data_ptr(),
+                                     gg.data_ptr() if gg is not None else None, gh.data_ptr() if gh is not None else None,
+                                     B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type], ws.data_ptr(), ws_bytes, stream)
+    _lib.check(rc, "cspn2d_backward_f32")
+    return gg, gh
+
+
 def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
     """gate [B,26,D,H,W], feat [B,1,D,H,W] -> [B,1,D,H,W]; n_iter fused 3x3x3 propagation steps."""
     lib = _lib.load()

@@ -73,6 +73,17 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
 /* which kernel AUTO would run for this shape: CSPN_ALGO_STEPWISE or CSPN_ALGO_FUSED */
 int cspn2d_auto_algo(int B, int H, int W, int n_iter);
 
+/* ---- 2D backward: the gradient torch autograd computes through Affinity_Propagate.forward (reference cspn.py:42-83),
+ * i.e. what reference cspn_pytorch/train.py:196-198 back-propagates through.
+ *   grad_out      [B,1,H,W]  dL/d(out)
+ *   grad_guidance [B,8,H,W]  dL/d(guidance), or NULL to skip
+ *   grad_blur     [B,1,H,W]  dL/d(blur_depth) (as level-0 value and as H_0 of the centre / mask terms), or NULL to skip
+ * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1. */
+size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter);
+int cspn2d_backward_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
+                        float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type,
+                        void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
 /* ---- 3D: replaces n_iter chained fluid.layers.affinity_propagate calls,
  * reference cspn_paddle/demo.py:41-43,50-52 (kernel_size == 3 only, demo.py:90)
  *   gate [B,26,D,H,W], feat [B,1,D,H,W], sparse [B,1,D,H,W] or NULL, out [B,1,D,H,W] */

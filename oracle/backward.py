@@ -1,0 +1,68 @@
+"""oracle/backward.py -- CPU restatement (numpy, float64 accumulation optional) of the gradient torch autograd computes
+through reference cspn_pytorch/models/cspn.py:42-83 (the path reference train.py:196-198 back-propagates through).
+TEST INFRASTRUCTURE ONLY; pinned by tests/golden/cspn2d_grad_golden.npz, which the unmodified reference produced
+(tests/golden/make_grad_golden.py).
+
+Forward, folded:  H_{t+1} = c' + sum_k w'_k * shift_k(H_t),  w'_k = (1-m) w_k,
+c' = (1-m)(1-sigma) H_0 + m H_0,  w_k = G_k / S,  S = sum_j |G_j|,  G_k(p) = g~_k(p + off_k) (0 outside), sigma = sum_k w_k.
+Adjoint: A_N = dL/dout;  dW'_k += A_{t+1} * shift_k(H_t);  dC += A_{t+1};  A_t = sum_k shift_k^T(w'_k * A_{t+1});
+then the chain through the fold and the normalisation (abs: d|x|/dx = sign(x), 0 at 0, as torch.abs)."""
+import numpy as np
+
+DY = [1, 1, 1, 0, 0, -1, -1, -1]
+DX = [1, 0, -1, 1, -1, 1, 0, -1]
+
+
+def _shift(a, dy, dx):
+    """out(p) = a(p + (dy,dx)), zero outside; a: [B,H,W]"""
+    B, H, W = a.shape
+    pad = np.zeros((B, H + 2, W + 2), a.dtype)
+    pad[:, 1:-1, 1:-1] = a
+    return pad[:, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+
+
+def cspn2d_backward_oracle(guidance, blur, sparse, grad_out, n_iter, norm_type="8sum", dtype=np.float32):
+    g = np.asarray(guidance, dtype)
+    h0 = np.asarray(blur, dtype)[:, 0]
+    go = np.asarray(grad_out, dtype)[:, 0]
+    B, _, H, W = g.shape
+    gt = np.abs(g) if norm_type == "8sum_abs" else g
+    with np.errstate(all="ignore"):
+        G = np.stack([_shift(gt[:, k], DY[k], DX[k]) for k in range(8)], 1)      # [B,8,H,W]
+        S = np.abs(G).sum(1)
+        w = G / S[:, None]
+        sigma = w.sum(1)
+        m = np.sign(np.asarray(sparse, dtype)[:, 0]) if sparse is not None else np.zeros_like(h0)
+        om = 1 - m
+        wp = om[:, None] * w
+        cp = om * (1 - sigma) * h0 + m * h0
+        # forward, keeping every H_t
+        hs = [h0]
+        for _ in range(n_iter):
+            ht = hs[-1]
+            acc = cp.copy()
+            for k in range(8):
+                acc = acc + wp[:, k] * _shift(ht, DY[k], DX[k])
+            hs.append(acc.astype(dtype))
+        A = go.copy()
+        dW = np.zeros_like(wp)
+        dC = np.zeros_like(h0)
+        for t in range(n_iter - 1, -1, -1):
+            ht = hs[t]
+            dC += A
+            for k in range(8):
+                dW[:, k] += A * _shift(ht, DY[k], DX[k])
+            An = np.zeros_like(A)
+            for k in range(8):
+                An += _shift(wp[:, k] * A, -DY[k], -DX[k])
+            A = An.astype(dtype)
+        dw = om[:, None] * (dW - (dC * h0)[:, None])
+        grad_blur = A + dC * (om * (1 - sigma) + m)
+        T1 = (dw * G).sum(1)
+        dG = dw / S[:, None] - np.sign(G) * (T1 / (S * S))[:, None]
+        gg = np.zeros_like(g)
+        for k in range(8):
+            gg[:, k] = _shift(dG[:, k], -DY[k], -DX[k])    # g_k(q) feeds pixel p = q - off_k only
+        if norm_type == "8sum_abs":
+            gg = gg * np.sign(g)
+    return hs[-1][:, None], gg.astype(np.float32), grad_blur[:, None].astype(np.float32)

@@ -41,3 +41,16 @@ def reference_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_t
     m = ref.Affinity_Propagate(n_iter, 3, norm_type)
     with torch.no_grad(), cuda_is_identity():
         return m(guidance, blur_depth, sparse_depth)
+
+
+def reference_grads(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, norm_type="8sum"):
+    """-> (out, dL/dguidance, dL/dblur_depth) of L = sum(out * grad_out), by torch autograd through the UNMODIFIED
+    reference forward (what reference cspn_pytorch/train.py:196-198 back-propagates through)."""
+    ref = load_reference_module()
+    m = ref.Affinity_Propagate(n_iter, 3, norm_type)
+    g = guidance.clone().requires_grad_(True)
+    h = blur_depth.clone().requires_grad_(True)
+    with cuda_is_identity():
+        out = m(g, h, sparse_depth)
+        gg, gh = torch.autograd.grad(out, [g, h], grad_out)
+    return out.detach(), gg, gh

@@ -1,0 +1,97 @@
+"""Backward of the 2D op: the gradient torch autograd computes through the reference forward
+(cspn.py:42-83), which reference train.py:196-198 back-propagates through.
+CPU: the numpy restatement (oracle/backward.py) against gradients the UNMODIFIED reference produced
+(tests/golden/cspn2d_grad_golden.npz, made by tests/golden/make_grad_golden.py).
+GPU: the HIP kernels through the C ABI / the autograd Function against those vectors and against the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_inputs
+from oracle.backward import cspn2d_backward_oracle
+
+GTOL = 2e-4  # relative to max|grad|: 1e-4 forward tolerance with headroom for the longer accumulation chains
+NORMS = {0: "8sum", 1: "8sum_abs"}
+
+
+def _golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cspn2d_grad_golden.npz"))
+    for n in sorted({k.split("/")[0] for k in z.files}):
+        c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")}
+        yield n, c
+
+
+def _err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert np.array_equal(np.isfinite(a), np.isfinite(b))
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_backward_oracle_vs_reference_autograd():
+    for name, c in _golden():
+        B, H, W, N, norm = (int(v) for v in c["meta"])
+        o, gg, gh = cspn2d_backward_oracle(c["guidance"], c["blur"], c.get("sparse"), c["grad_out"], N, NORMS[norm])
+        assert _err(o, c["out"]) <= 1e-5, name
+        assert _err(gg, c["grad_guidance"]) <= 1e-5, name
+        assert _err(gh, c["grad_blur"]) <= 1e-5, name
+
+
+@pytest.mark.gpu
+def test_hip_backward_vs_reference_autograd_goldens():
+    import cspn_amd
+    for name, c in _golden():
+        B, H, W, N, norm = (int(v) for v in c["meta"])
+        t = {k: torch.from_numpy(v).cuda() for k, v in c.items() if k != "meta"}
+        gg, gh = cspn_amd.cspn2d_backward(t["guidance"], t["blur"], t.get("sparse"), t["grad_out"], N, NORMS[norm])
+        torch.cuda.synchronize()
+        assert _err(gg.cpu().numpy(), c["grad_guidance"]) <= GTOL, name
+        assert _err(gh.cpu().numpy(), c["grad_blur"]) <= GTOL, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,N,norm,sp", [(2, 37, 53, 24, "8sum", True), (1, 64, 320, 24, "8sum_abs", True),
+                                             (3, 20, 256, 12, "8sum", False), (1, 5, 9, 1, "8sum_abs", False),
+                                             (1, 30, 40, 30, "8sum", True)])
+def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
+    import cspn_amd
+    g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp)
+    go = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(5))
+    _, rgg, rgh = cspn2d_backward_oracle(g.numpy(), h.numpy(), None if s is None else s.numpy(), go.numpy(), N, norm)
+    gd, hd = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    m = cspn_amd.Affinity_Propagate(N, 3, norm)
+    out = m(gd, hd, None if s is None else s.cuda())
+    out.backward(go.cuda())
+    assert _err(gd.grad.cpu().numpy(), rgg) <= GTOL
+    assert _err(hd.grad.cpu().numpy(), rgh) <= GTOL
+    # only one input needs a gradient: the other output is skipped
+    hd2 = h.cuda().requires_grad_(True)
+    m(g.cuda(), hd2, None if s is None else s.cuda()).backward(go.cuda())
+    assert _err(hd2.grad.cpu().numpy(), rgh) <= GTOL
+
+
+@pytest.mark.gpu
+def test_hip_backward_full_size_is_linear_in_grad_out():
+    import cspn_amd
+    B, H, W = 4, 304, 1216
+    g, h, s = make_inputs(B, H, W, seed=11, sparse=True)
+    gd, hd, sd = g.cuda(), h.cuda(), s.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    a, b = torch.randn(B, 1, H, W, generator=gen, device="cuda"), torch.randn(B, 1, H, W, generator=gen, device="cuda")
+    ga, ha = cspn_amd.cspn2d_backward(gd, hd, sd, a, 24, "8sum")
+    gb, hb = cspn_amd.cspn2d_backward(gd, hd, sd, b, 24, "8sum")
+    gc, hc = cspn_amd.cspn2d_backward(gd, hd, sd, 2.0 * a - 0.5 * b, 24, "8sum")
+    assert torch.isfinite(gc).all() and torch.isfinite(hc).all()
+    assert float((gc - (2.0 * ga - 0.5 * gb)).abs().max() / gc.abs().max()) <= GTOL
+    assert float((hc - (2.0 * ha - 0.5 * hb)).abs().max() / hc.abs().max()) <= GTOL
+    # masked pixels: their output is H_0 itself, so d out / d blur carries the full grad_out there
+    one = cspn2d_backward_check_mask(cspn_amd, gd, hd, sd)
+    assert one
+
+
+def cspn2d_backward_check_mask(cspn_amd, gd, hd, sd):
+    # with grad_out = indicator of the masked pixels only, every masked pixel's own blur gradient contains that 1
+    mask = (sd != 0).float()
+    _, hb = cspn_amd.cspn2d_backward(gd, hd, sd, mask, 24, "8sum")
+    return bool(((hb - 1.0)[mask.bool()] >= -1e-4).all())

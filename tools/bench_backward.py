@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""tools/bench_backward.py -- time the 2D backward (cspn2d_backward_f32) at BASELINE config 3's image size.
+One JSON line: ms per backward call, pix*iters/s, and the fraction of the 8 TB/s roofline priced with the algorithmic
+bytes of a gradient computation that touches every tensor once (guidance 32 + blur 4 + grad_out 4 in, grad_guidance 32 +
+grad_blur 4 out = 76 B/pixel, + 4 with a sparse mask)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cspn_amd  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--sparse", action="store_true")
+    a = ap.parse_args()
+    B, H, W, N = a.batch, 304, 1216, 24
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    g = torch.randn(B, 8, H, W, generator=gen, device="cuda")
+    h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
+    s = None
+    if a.sparse:
+        s = (torch.rand(B, 1, H, W, generator=gen, device="cuda") < 500.0 / (H * W)).float() * (h + 0.1)
+    go = torch.randn(B, 1, H, W, generator=gen, device="cuda")
+    for _ in range(3):
+        cspn_amd.cspn2d_backward(g, h, s, go, N, "8sum")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cspn_amd.cspn2d_backward(g, h, s, go, N, "8sum")
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    px = B * H * W
+    alg = px * (80 if a.sparse else 76)
+    print(json.dumps({"op": "cspn2d_backward_f32", "B": B, "H": H, "W": W, "n_iter": N, "sparse": a.sparse,
+                      "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
+                      "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
+                      "note": "first version: stepwise (fold + 23 forward steps for the H_t history + 24 adjoint steps + 1 "
+                              "final pass); workspace (2*n_iter + 8) planes"}))
+
+
+if __name__ == "__main__":
+    main()
