@@ -56,6 +56,16 @@ def load():
     lib.cspn2d_backward_workspace_bytes.argtypes = [c_int] * 4
     lib.cspn2d_backward_f32.restype = c_int
     lib.cspn2d_backward_f32.argtypes = [vp] * 6 + [c_int] * 5 + [vp, c_size_t, vp]
+    lib.cspn_metrics_workspace_bytes.restype = c_size_t
+    lib.cspn_metrics_workspace_bytes.argtypes = [c_size_t]
+    lib.cspn_metrics_f32.restype = c_int
+    lib.cspn_metrics_f32.argtypes = [vp, vp, c_size_t, vp, vp, c_size_t, vp]
+    lib.cspn_l1_backward_f32.restype = c_int
+    lib.cspn_l1_backward_f32.argtypes = [vp, vp, vp, vp, vp, c_size_t, vp]
+    lib.cspn_unpool_f32.restype = c_int
+    lib.cspn_unpool_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
+    lib.cspn_unpool_backward_f32.restype = c_int
+    lib.cspn_unpool_backward_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
     lib.cspn3d_workspace_bytes.restype = c_size_t
     lib.cspn3d_workspace_bytes.argtypes = [c_int] * 5
     lib.cspn3d_forward_f32.restype = c_int

@@ -1,0 +1,110 @@
+"""Device-side mirrors of the small steps next to the propagation path in the reference training / evaluation loops
+(SURVEY.md §8f-3, §8f-4), same names and call signatures:
+
+    reference                                                   here
+    utils.evaluate_error(gt_depth, pred_depth)   utils.py:19-47   evaluate_error(gt_depth, pred_depth) -> same dict, one
+                                                                  fused masked reduction on the GPU, one 48-byte copy back
+    loss.Wighted_L1_Loss()(pred, label)          loss.py:16-23    Wighted_L1_Loss()(pred, label) -> 0-d tensor, differentiable
+    Unpool(num_channels, stride=2)(x)            torch_resnet_cspn_nyu.py:41-54   Unpool(num_channels, stride)(x), differentiable
+
+The reference moves every prediction to the host before reducing it (train.py:204-206, eval.py:146-150)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .functional import _prep, _workspace
+
+_KEYS = ['MSE', 'RMSE', 'ABS_REL', 'LG10', 'MAE', 'DELTA1.02', 'DELTA1.05', 'DELTA1.10', 'DELTA1.25', 'DELTA1.25^2',
+         'DELTA1.25^3']
+
+
+def _metrics(gt, pred):
+    """-> device float32[12]: n_valid, then the 11 values of _KEYS"""
+    lib = _lib.load()
+    g = _prep(gt, "gt_depth")
+    p = _prep(pred, "pred_depth", tuple(g.shape))
+    out = torch.empty(12, dtype=torch.float32, device=g.device)
+    n = g.numel()
+    with torch.cuda.device(g.device):
+        wsb = lib.cspn_metrics_workspace_bytes(n)
+        ws = _workspace(wsb, g.device)
+        rc = lib.cspn_metrics_f32(g.data_ptr(), p.data_ptr(), n, out.data_ptr(), ws.data_ptr(), wsb,
+                                  torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn_metrics_f32")
+    return out
+
+
+def evaluate_error(gt_depth, pred_depth):
+    """reference utils.py:19-47: dict of python floats (0 everywhere when no pixel has gt > 1e-4)"""
+    v = _metrics(gt_depth, pred_depth).tolist()
+    return {k: v[i + 1] for i, k in enumerate(_KEYS)}
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, label):
+        stats = _metrics(label, pred)
+        ctx.save_for_backward(pred, label, stats)
+        # MAE over label > 1e-4 == loss.py:18-22; nothing valid: loss.py:21-22 computes 0/0 = nan
+        return torch.where(stats[0] > 0, stats[5], stats[5] + float("nan"))
+
+    @staticmethod
+    def backward(ctx, grad):
+        pred, label, stats = ctx.saved_tensors
+        lib = _lib.load()
+        p, l = pred.contiguous(), label.contiguous()
+        gp = torch.empty_like(p)
+        gs = grad.reshape(1).to(torch.float32).contiguous()
+        with torch.cuda.device(p.device):
+            rc = lib.cspn_l1_backward_f32(p.data_ptr(), l.data_ptr(), stats.data_ptr(), gs.data_ptr(), gp.data_ptr(), p.numel(),
+                                          torch.cuda.current_stream(p.device).cuda_stream)
+        _lib.check(rc, "cspn_l1_backward_f32")
+        return gp.view_as(pred), None
+
+
+class Wighted_L1_Loss(nn.Module):
+    """reference loss.py:12-23 (spelling as there)"""
+
+    def forward(self, pred, label):
+        return _L1.apply(pred, label)
+
+
+class _Unpool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        lib = _lib.load()
+        xc = _prep(x, "x")
+        N, C, H, W = xc.shape
+        out = torch.empty(N, C, H * stride, W * stride, dtype=torch.float32, device=xc.device)
+        ctx.shape, ctx.stride = (N, C, H, W), stride
+        with torch.cuda.device(xc.device):
+            rc = lib.cspn_unpool_f32(xc.data_ptr(), out.data_ptr(), N * C, H, W, stride,
+                                     torch.cuda.current_stream(xc.device).cuda_stream)
+        _lib.check(rc, "cspn_unpool_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        N, C, H, W = ctx.shape
+        g = go.contiguous()
+        gx = torch.empty(N, C, H, W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.cspn_unpool_backward_f32(g.data_ptr(), gx.data_ptr(), N * C, H, W, ctx.stride,
+                                              torch.cuda.current_stream(g.device).cuda_stream)
+        _lib.check(rc, "cspn_unpool_backward_f32")
+        return gx, None
+
+
+class Unpool(nn.Module):
+    """reference torch_resnet_cspn_nyu.py:41-54: stride x stride unpooling with zero padding (no parameters)"""
+
+    def __init__(self, num_channels, stride=2):
+        super(Unpool, self).__init__()
+        self.num_channels = num_channels
+        self.stride = stride
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.num_channels:
+            raise ValueError("expected [N,%d,H,W], got %s" % (self.num_channels, tuple(x.shape)))
+        return _Unpool.apply(x, self.stride)

@@ -92,6 +92,23 @@ int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse
                        int B, int D, int H, int W, int n_iter, int norm_type,
                        void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
+/* ---- the steps right next to the path, on the device ----
+ * cspn_metrics_f32: reference cspn_pytorch/utils.py:19-47 (evaluate_error) and loss.py:16-23 (Wighted_L1_Loss = MAE
+ * over gt > 1e-4) as one fused masked reduction over n elements.  out12 (device, 12 floats):
+ *   [0] n_valid  [1] MSE  [2] RMSE  [3] ABS_REL  [4] LG10 (the reference never fills it: 0)  [5] MAE
+ *   [6..11] DELTA1.02, 1.05, 1.10, 1.25, 1.25^2, 1.25^3.   All zero when no element is valid (utils.py:23-26).
+ * cspn_l1_backward_f32: d(Wighted_L1_Loss)/d(pred) = grad_scale[0] * sign(pred - label) / n_valid on label > 1e-4;
+ *   stats12 = the out12 of cspn_metrics_f32(label, pred), grad_scale = 1 device float.
+ * cspn_unpool_f32: reference models/torch_resnet_cspn_nyu.py:41-54 (Unpool: conv_transpose2d with a one-hot
+ *   stride x stride kernel): out[nc][y*stride][x*stride] = x[nc][y][x], zeros elsewhere; x [NC,H,W] -> out [NC,H*s,W*s]. */
+size_t cspn_metrics_workspace_bytes(size_t n);
+int cspn_metrics_f32(const float* gt, const float* pred, size_t n, float* out12, void* workspace, size_t workspace_bytes,
+                     cspn_stream_t stream);
+int cspn_l1_backward_f32(const float* pred, const float* label, const float* stats12, const float* grad_scale,
+                         float* grad_pred, size_t n, cspn_stream_t stream);
+int cspn_unpool_f32(const float* x, float* out, size_t NC, int H, int W, int stride, cspn_stream_t stream);
+int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, int H, int W, int stride, cspn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
