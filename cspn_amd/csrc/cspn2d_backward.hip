@@ -22,8 +22,27 @@ __global__ void step2d_kernel(const float* __restrict__ wf, const float* __restr
 
 namespace {
 
-// A_t(p) = sum_k w'_k(q) A_{t+1}(q),  q = p - off_k inside the image
-__global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__ wf, const float* __restrict__ ain,
+// wt_k(p) = w'_k(p - off_k) (0 outside): the adjoint stencil then reads its eight coefficient planes at p itself, like
+// the forward step does
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ wf, float* __restrict__ wt, int B, int H,
+                                                           int W) {
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = (int)(idx / HW);
+    const int r = (int)(idx - (size_t)b * HW);
+    const int y = r / W, x = r - y * W;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int yy = y - dy2(k), xx = x - dx2(k);
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = wf[k * total + (size_t)b * HW + (size_t)yy * W + xx];
+        wt[k * total + idx] = v;
+    }
+}
+
+// A_t(p) = sum_k wt_k(p) A_{t+1}(p - off_k)
+__global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__ wt, const float* __restrict__ ain,
                                                         float* __restrict__ aout, int B, int H, int W) {
     const size_t HW = (size_t)H * W, total = (size_t)B * HW;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,10 +55,9 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int yy = y - dy2(k), xx = x - dx2(k);
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const size_t q = base + (size_t)yy * W + xx;
-            acc = fmaf(wf[k * total + q], ain[q], acc);
-        }
+        float a = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) a = ain[base + (size_t)yy * W + xx];
+        acc = fmaf(wt[k * total + idx], a, acc);
     }
     aout[idx] = acc;
 }
@@ -122,14 +140,15 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
 
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
-    return (size_t)(9 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
+    return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
                int W, int n_iter, int norm, void* ws, hipStream_t st) {
     const size_t total = (size_t)B * H * W;
     float* wf = (float*)ws;
-    float* hh = wf + 9 * total;                       // H_1 .. H_{N-1}
+    float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
+    float* hh = wt + 8 * total;                       // H_1 .. H_{N-1}
     float* ah = hh + (size_t)(n_iter - 1) * total;    // A_0 .. A_{N-1}
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(fold2d_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, wf, B, H, W, norm);
@@ -137,8 +156,9 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
     for (int t = 1; t < n_iter; ++t)
         hipLaunchKernelGGL(step2d_kernel, dim3(blocks), dim3(256), 0, st, wf, t == 1 ? blur : hh + (size_t)(t - 2) * total,
                            hh + (size_t)(t - 1) * total, B, H, W);
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(blocks), dim3(256), 0, st, wf, wt, B, H, W);
     for (int t = n_iter - 1; t >= 0; --t)
-        hipLaunchKernelGGL(bwd_step_kernel, dim3(blocks), dim3(256), 0, st, wf,
+        hipLaunchKernelGGL(bwd_step_kernel, dim3(blocks), dim3(256), 0, st, wt,
                            t == n_iter - 1 ? gout : ah + (size_t)(t + 1) * total, ah + (size_t)t * total, B, H, W);
     if (int e = check_launch("bwd_step_kernel")) return e;
     if (gg && norm != CSPN_NORM_NONE) {

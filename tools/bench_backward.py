@@ -44,7 +44,7 @@ def main():
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
                       "note": "first version: stepwise (fold + 23 forward steps for the H_t history + 24 adjoint steps + 1 "
-                              "final pass); workspace (2*n_iter + 8) planes"}))
+                              "final pass); workspace (2*n_iter + 16) planes"}))
 
 
 if __name__ == "__main__":
