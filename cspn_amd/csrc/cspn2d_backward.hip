@@ -41,6 +41,26 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
     }
 }
 
+// The adjoint sweep as a propagation the forward kernel can run (norm_type NONE: gates used as given, centre-sited):
+//   A_t(p) = sum_k w'_k(p - off_k) A_{t+1}(p - off_k) = sum_k' G_k'(p) A_{t+1}(p + off_k'),  k' = 7 - k (off_{7-k} = -off_k),
+//   G_k'(p) = w'_{7-k'}(p + off_k') (0 outside).  gt: [B,8,H,W]
+__global__ __launch_bounds__(256) void transpose_rev_kernel(const float* __restrict__ wf, float* __restrict__ gt, int B, int H,
+                                                             int W) {
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = (int)(idx / HW);
+    const int r = (int)(idx - (size_t)b * HW);
+    const int y = r / W, x = r - y * W;
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+        const int yy = y + dy2(kp), xx = x + dx2(kp);
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = wf[(size_t)(7 - kp) * total + (size_t)b * HW + (size_t)yy * W + xx];
+        gt[((size_t)b * 8 + kp) * HW + r] = v;
+    }
+}
+
 // A_t(p) = sum_k wt_k(p) A_{t+1}(p - off_k)
 __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__ wt, const float* __restrict__ ain,
                                                         float* __restrict__ aout, int B, int H, int W) {
@@ -62,10 +82,18 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__
     aout[idx] = acc;
 }
 
-// hh: H_1 .. H_{N-1} (H_0 = blur); ah: A_0 .. A_{N-1} (A_N = grad_out)
+__device__ __forceinline__ size_t swz(size_t i) {  // register order (c0,c2,c1,c3) inside each aligned group of 4 columns
+    const size_t e = i & 3;
+    return (i & ~(size_t)3) | (e == 1 ? 2 : (e == 2 ? 1 : e));
+}
+
+// hh: H_1 .. H_{N-1} (H_0 = blur).  SWZ = false: ah = A_0 .. A_{N-1}, plain layout (stepwise sweeps).
+// SWZ = true (assembly passes, N = 24): hh and ah are level histories in register order; ah level n = A_{24-n}, a0p = A_0.
+template <bool SWZ>
 __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict__ g, const float* __restrict__ blur,
                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
-                                                         const float* __restrict__ ah, const float* __restrict__ gout,
+                                                         const float* __restrict__ ah, const float* __restrict__ a0p,
+                                                         const float* __restrict__ gout,
                                                          float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W,
                                                          int n_iter, int norm) {
     const size_t HW = (size_t)H * W, total = (size_t)B * HW;
@@ -85,16 +113,22 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
     }
     float dW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dC = 0.f;
     for (int t = 0; t < n_iter; ++t) {
-        const float a = (t + 1 == n_iter) ? gout[idx] : ah[(size_t)(t + 1) * total + idx];
+        float a;
+        if (t + 1 == n_iter) a = gout[idx];
+        else a = SWZ ? ah[(size_t)(n_iter - 2 - t) * total + swz(idx)] : ah[(size_t)(t + 1) * total + idx];
         const float* ht = (t == 0) ? blur : hh + (size_t)(t - 1) * total;
         dC += a;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dW[k] = fmaf(a, ok[k] ? ht[base + noff[k]] : 0.f, dW[k]);
+        for (int k = 0; k < 8; ++k) {
+            float hv = 0.f;
+            if (ok[k]) hv = (SWZ && t > 0) ? ht[swz(base + noff[k])] : ht[base + noff[k]];
+            dW[k] = fmaf(a, hv, dW[k]);
+        }
     }
     const float h0 = blur[idx];
     const float m = sparse ? signf(sparse[idx]) : 0.f;
     const float om = 1.f - m;
-    const float a0 = ah[idx];
+    const float a0 = SWZ ? a0p[idx] : ah[idx];
     const float* gbp = g + (size_t)b * 8 * HW;
     if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
         if (gb) gb[idx] = a0 + dC * m;
@@ -138,8 +172,12 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
 
 }  // namespace
 
+static bool asm_path(int B, int H, int W, int n_iter) { return n_iter == 24 && tsw2d_supported(B, H, W); }
+
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
+    if (asm_path(B, H, W, n_iter))  // folded 9 + transposed 8 + two 23-level histories + A_0 + a scratch output, then the plan
+        return (size_t)(9 + 8 + 23 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
@@ -147,6 +185,30 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
                int W, int n_iter, int norm, void* ws, hipStream_t st) {
     const size_t total = (size_t)B * H * W;
     float* wf = (float*)ws;
+    if (asm_path(B, H, W, n_iter)) {
+        // both sweeps run in the fused ring kernel (cspn2d_tsw.hip), each writing its 23 intermediate levels: the forward
+        // as it is, the adjoint as a norm_type-NONE propagation over transposed coefficients
+        float* gt = wf + 9 * total;
+        float* hh = gt + 8 * total;
+        float* ah = hh + 23 * total;
+        float* a0 = ah + 23 * total;
+        float* scratch = a0 + total;
+        void* plan = (void*)(((uintptr_t)(scratch + total) + 255) & ~(uintptr_t)255);
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
+        if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, plan, st, hh)) return e;
+        hipLaunchKernelGGL(fold2d_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, wf, B, H, W, norm);
+        hipLaunchKernelGGL(transpose_rev_kernel, dim3(blocks), dim3(256), 0, st, wf, gt, B, H, W);
+        if (int e = check_launch("transpose_rev_kernel")) return e;
+        if (int e = tsw2d_pass(gt, gout, gout, nullptr, a0, B, H, W, CSPN_NORM_NONE, plan, st, ah)) return e;
+        if (gg && norm != CSPN_NORM_NONE) {
+            hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
+            if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
+                           H, W, n_iter, norm);
+        return check_launch("bwd_final_kernel");
+    }
     float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
     float* hh = wt + 8 * total;                       // H_1 .. H_{N-1}
     float* ah = hh + (size_t)(n_iter - 1) * total;    // A_0 .. A_{N-1}
@@ -165,8 +227,8 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
         if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(bwd_final_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, gout, gg, gb, B, H, W, n_iter,
-                       norm);
+    hipLaunchKernelGGL(bwd_final_kernel<false>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, nullptr, gout, gg, gb, B,
+                       H, W, n_iter, norm);
     return check_launch("bwd_final_kernel");
 }
 

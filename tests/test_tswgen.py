@@ -32,12 +32,22 @@ def test_emulated_asm_loop_vs_oracle(B, H, W, n_wg, norm, sparse, hin, zp):
         assert np.isnan(ref).any()
 
 
+def test_emulated_history_variant_writes_every_level():
+    """cfg hist (used by the backward pass): levels 1..23 of every owned pixel, checked against the oracle level by level"""
+    os.chdir(ROOT)
+    err, nanmis, _, _ = run_case(2, 11, 304, 4, 0, True, False, seed=3, verbose=False, hist=True)
+    assert nanmis == 0 and err <= 1e-4
+
+
 def test_generated_include_is_current_and_hazard_free():
     inc = open(os.path.join(ROOT, "cspn_amd", "csrc", "cspn2d_tsw_gen.inc")).read()
     for norm, sparse, hin in ((0, 0, 0), (1, 1, 1), (2, 1, 0)):
         p = K.build(dict(norm=norm, sparse=bool(sparse), hin=bool(hin)))
         assert not check_hazards(p)
         assert ("#define TSW_ASM_%d_%d_%d R\"ASM(\n%s\n)ASM\"" % (norm, sparse, hin, p.text())) in inc
+    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True))
+    assert not check_hazards(p)
+    assert ("#define TSW_ASM_HIST_2_0 R\"ASM(\n%s\n)ASM\"" % p.text()) in inc
 
 
 def test_scheduler_respects_hazards_and_emulator_flags_misuse():

@@ -43,8 +43,8 @@ def main():
     print(json.dumps({"op": "cspn2d_backward_f32", "B": B, "H": H, "W": W, "n_iter": N, "sparse": a.sparse,
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
-                      "note": "first version: stepwise (fold + 23 forward steps for the H_t history + 24 adjoint steps + 1 "
-                              "final pass); workspace (2*n_iter + 16) planes"}))
+                      "note": "forward and adjoint sweeps each as one launch of the fused ring kernel writing its 23 intermediate "
+                              "levels, + fold / transpose / final pass; workspace 65 planes + the row-descriptor table"}))
 
 
 if __name__ == "__main__":

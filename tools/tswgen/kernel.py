@@ -36,6 +36,7 @@ V_OFFK = [V(12 + k) for k in range(8)]
 V_OFF1 = V(20)
 V_TMP = V(21)
 V_DE, V_DO, V_DC = V(21), V(22, 2), V(252, 4)  # descriptor fetches (event: new row's d3, old row's d2:d3; cooking: whole row)
+V_DN = V(74, 2)                                 # history mode: new row's d2:d3
 TQ, BQ, TA, TB, HN, HA, OUTQ = V(24, 4), V(28, 4), V(32, 4), V(36, 4), V(40, 4), V(44, 4), V(48, 4)
 CK = V(24, 28)  # cooking temporaries alias the step temporaries
 PEND_G = [V(52 + 2 * k, 2) for k in range(8)]
@@ -62,6 +63,11 @@ S_ENF = S(44)                   # event: the entering row's descriptor dword 3 (
 S_EO = S(48, 2)                 # event: the retiring row's descriptor dwords 2:3 (boff, flags | lo | hi)
 S_CD = S(60, 4)                 # cooking: descriptor of the task being requested
 S_TABB = S(37)                  # LDS address of descriptor row 0 (table base + PADF rows)
+# history mode (cfg hist): every level 1..23 of every owned row is also written out (the backward pass needs all H_t)
+S_HIST, S_HSTRIDE = S(92, 2), S(94, 2)       # inputs: base of the level-1 plane, bytes from one level's plane to the next
+S_ENB = S(46)                                   # entering row's descriptor dword 2 (byte offset in a 1-channel tensor)
+S_HB = [S(84, 2), S(86, 2), S(88, 2), S(90, 2)]     # per slot: where the row's next level goes
+S_HM = [S(0, 2), S(4, 2), S(96, 2), S(98, 2)]       # per slot: lanes that own columns of the row (0: halo / inactive row)
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
 S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
 GB_UP, GB_MID, GB_DN, B_BLUR, B_HIN, B_SP = S(0, 2), S(2, 2), S(4, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task
@@ -72,6 +78,7 @@ class Gen(object):
         self.cfg = cfg
         self.p = Prog()
         self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
+        self.hist = cfg.get("hist", False)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
@@ -138,8 +145,12 @@ class Gen(object):
     def fetch_event(self, ev):
         """LDS reads of the descriptors the event of slot ev needs (issued with the boundary-row reads)"""
         self.desc_addr(T[0], S_QB, ev)
-        self.mov(V_DE, T[0])
-        self.e("ds_read_b32", V_DE, [V_DE], offset=12, at=0.0)
+        if self.hist:
+            self.mov(V_DN[0], T[0])
+            self.e("ds_read_b64", V_DN, [V_DN[0]], offset=8, at=0.0)
+        else:
+            self.mov(V_DE, T[0])
+            self.e("ds_read_b32", V_DE, [V_DE], offset=12, at=0.0)
         self.e("s_add_i32", T[1], [T[0], -32 * DESC_BYTES])
         self.mov(V_DO[0], T[1])
         self.e("ds_read_b64", V_DO, [V_DO[0]], offset=8, at=0.0)
@@ -150,7 +161,11 @@ class Gen(object):
         self.e("ds_read_b128", V_DC, [V_DC[0]], at=0.0)
 
     def take_event(self):
-        self.e("v_readfirstlane_b32", S_ENF, [V_DE])
+        if self.hist:
+            self.e("v_readfirstlane_b32", S_ENB, [V_DN[0]])
+            self.e("v_readfirstlane_b32", S_ENF, [V_DN[1]])
+        else:
+            self.e("v_readfirstlane_b32", S_ENF, [V_DE])
         self.e("v_readfirstlane_b32", S_EO[0], [V_DO[0]])
         self.e("v_readfirstlane_b32", S_EO[1], [V_DO[1]])
 
@@ -196,6 +211,24 @@ class Gen(object):
         self.e("s_or_b32", S_ACT, [S_ACT, T[2]])
         if j == 3:
             self.e("s_add_i32", S_QB, [S_QB, 32])
+        if self.hist:  # where the row's levels go and which lanes own its columns
+            self.e("s_bfe_u32", T[2], [S_ENF, 8 | (9 << 16)])
+            self.e("s_bfe_u32", T[3], [S_ENF, 20 | (9 << 16)])
+            self.e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
+            self.e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
+            self.e("s_and_b64", S(T[4].i, 2), [S(T[4].i, 2), S(T[6].i, 2)])
+            self.e("s_bitcmp1_b32", (), [S_ENF, F_OWNED])
+            self.e("s_cselect_b64", S_HM[j], [S(T[4].i, 2), 0])
+            self.e("s_add_u32", S_HB[j][0], [S_HIST[0], S_ENB])
+            self.e("s_addc_u32", S_HB[j][1], [S_HIST[1], 0])
+
+    def hist_store(self, j, vq):
+        """history mode: the level slot j just completed (1..23), in register order (c0,c2,c1,c3) per 4-column group"""
+        self.e("s_mov_b64", EXEC, [S_HM[j]])
+        self.e("global_store_dwordx4", (), [V_L16, vq, S_HB[j]])
+        self.e("s_mov_b64", EXEC, [-1])
+        self.e("s_add_u32", S_HB[j][0], [S_HB[j][0], S_HSTRIDE[0]])
+        self.e("s_addc_u32", S_HB[j][1], [S_HB[j][1], S_HSTRIDE[1]])
 
     # event planes: the coefficient planes of slot j that are dead when the event step starts (the row in the slot only
     # needs its below taps -- and, for slot 0, its above taps -- to finish its last level) can be replaced at the top of
@@ -294,6 +327,8 @@ class Gen(object):
                 self.inject(j, vq)
             elif "noact" not in self.ab:
                 self.act_check(j, vq)
+            if self.hist and ev != j:
+                self.hist_store(j, vq)
             if j == 3 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024, at=0.0)
             if j == 0 and "nolds" not in self.ab:
@@ -498,6 +533,10 @@ class Gen(object):
             self.mov(q[1], 0)
         e("s_mov_b32", S_TAU, [0])
         e("s_mov_b32", S_ACT, [0])
+        if self.hist:
+            for j in range(4):
+                e("s_mov_b64", S_HM[j], [0])
+                e("s_mov_b64", S_HB[j], [S_HIST])
         e("s_and_b32", T[1], [S_WV, 1])            # T1 = wave parity (= cooking half)
         e("s_lshr_b32", T[2], [S_WV, 1])           # T2 = wv >> 1
         # boundary exchange addresses

@@ -10,7 +10,7 @@ from .emu import Emu, EmuError
 from .plan import build_plan
 
 
-def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True):
+def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False):
     sys.path.insert(0, ".")
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
@@ -29,7 +29,8 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     hinv = None
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
-    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin), sched=sched)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist), sched=sched)
+    histbuf = np.full((23, B, 1, H, W), np.nan, np.float32) if hist else None
     from .plan import plan_bands
     nb = len(plan_bands(W, n_iter))
     n_wg = -(-n_wg // nb) * nb   # whole groups of nb workgroups
@@ -38,7 +39,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     def al(n):
         return (n + 4095) // 4096 * 4096
     off, cur = {}, 8192
-    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("out", np.zeros_like(blur)), ("plan", tab)):
+    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("out", np.zeros_like(blur)), ("plan", tab), ("hist", histbuf)):
         if arr is None:
             off[name] = 4096
             continue
@@ -68,6 +69,9 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             set64(K.S_OUT, off["out"])
             set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16)
             w.s[K.S_NROWS.i] = tab.shape[1]
+            if hist:
+                set64(K.S_HIST, off["hist"])
+                set64(K.S_HSTRIDE, blur.nbytes)
             w.s[K.S_W4.i] = 4 * W
             w.s[K.S_HW4.i] = 4 * H * W
             w.s[K.S_LAST.i] = int(hdr[wg, 1])
@@ -82,6 +86,18 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         ref = ref_hin(g, blur, sp, hinv, n_iter, norm)
     else:
         ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none"][norm])
+    if hist:
+        assert not hin
+        hb = mem[off["hist"]:off["hist"] + histbuf.nbytes].view(np.float32).reshape(23, B, H, W // 4, 4)
+        hb = hb[..., [0, 2, 1, 3]].reshape(23, B, 1, H, W)   # stored in register order (c0,c2,c1,c3) per 4-column group
+        worst = 0.0
+        for lv in range(1, 24):
+            r = O.cspn2d_oracle(g, blur, sp, lv, ["8sum", "8sum_abs", "none"][norm])
+            assert np.array_equal(np.isnan(hb[lv - 1]), np.isnan(r)), "history level %d: NaN pattern" % lv
+            worst = max(worst, float(np.nanmax(np.abs(hb[lv - 1] - r)) / np.nanmax(np.abs(r))))
+        if verbose:
+            print("   history levels 1..23: worst rel err %.3g" % worst)
+        assert worst <= 1e-5
     nanmis = np.isnan(out) != np.isnan(ref)
     den = np.nanmax(np.abs(ref))
     err = np.nanmax(np.abs(out - ref)) / den if not nanmis.any() else np.inf
