@@ -70,7 +70,7 @@ S_HB = [S(84, 2), S(86, 2), S(88, 2), S(90, 2)]     # per slot: where the row's 
 S_HM = [S(0, 2), S(4, 2), S(96, 2), S(98, 2)]       # per slot: lanes that own columns of the row (0: halo / inactive row)
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
 S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
-GB_UP, GB_MID, GB_DN, B_BLUR, B_HIN, B_SP = S(0, 2), S(2, 2), S(4, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task
+GB_MID, B_BLUR, B_HIN, B_SP = S(2, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task (s0:1, s4:5: S_HM)
 
 
 class Gen(object):
