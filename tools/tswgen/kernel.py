@@ -57,6 +57,8 @@ S_GD, S_BLUR, S_HIN, S_SP, S_OUT, S_PLAN = S(16, 2), S(18, 2), S(20, 2), S(22, 2
 S_W4, S_HW4, S_LAST, S_WV = S(28), S(29), S(30), S(31)
 S_LDSB = S(15)  # LDS base address of the kernel's __shared__ block
 S_NROWS = S(14)  # descriptors in this workgroup's table (<= TAB_MAX_ROWS)
+S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16 (one band per workgroup)
+S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
 S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(32), S(33), S(34), S(35), S(36)
 S_EL, S_ER = S(38, 2), S(40, 2)
 S_ENF = S(44)                   # event: the entering row's descriptor dword 3 (flags)
@@ -180,21 +182,16 @@ class Gen(object):
         self.e("s_cbranch_scc0", (), [lab])
         self.e("s_bitcmp1_b32", (), [eo[1], F_OWNED])
         self.e("s_cbranch_scc0", (), [lab])
-        self.e("s_bfe_u32", T[2], [eo[1], 8 | (9 << 16)])
-        self.e("s_bfe_u32", T[3], [eo[1], 20 | (9 << 16)])
-        self.e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
-        self.e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
-        self.e("s_and_b64", S(T[4].i, 2), [S(T[4].i, 2), S(T[6].i, 2)])
         self.mov(OUTQ[0], vq[0])
         self.mov(OUTQ[1], vq[2])
         self.mov(OUTQ[2], vq[1])
         self.mov(OUTQ[3], vq[3])
         self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
         self.e("s_addc_u32", T[9], [S_OUT[1], 0])
-        self.e("s_and_saveexec_b64", S(T[6].i, 2), [S(T[4].i, 2)])
+        self.e("s_mov_b64", EXEC, [S_OMASK])   # the owned columns are the same for every row of this workgroup's band
         if "nostore" not in self.ab:
             self.e("global_store_dwordx4", (), [V_L16, OUTQ, S(T[8].i, 2)], cache=self.cfg.get("st_cache"))
-        self.e("s_mov_b64", EXEC, [S(T[6].i, 2)])
+        self.e("s_mov_b64", EXEC, [-1])
         self.p.label(lab)
 
     def inject(self, j, vq):
@@ -212,13 +209,8 @@ class Gen(object):
         if j == 3:
             self.e("s_add_i32", S_QB, [S_QB, 32])
         if self.hist:  # where the row's levels go and which lanes own its columns
-            self.e("s_bfe_u32", T[2], [S_ENF, 8 | (9 << 16)])
-            self.e("s_bfe_u32", T[3], [S_ENF, 20 | (9 << 16)])
-            self.e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
-            self.e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
-            self.e("s_and_b64", S(T[4].i, 2), [S(T[4].i, 2), S(T[6].i, 2)])
             self.e("s_bitcmp1_b32", (), [S_ENF, F_OWNED])
-            self.e("s_cselect_b64", S_HM[j], [S(T[4].i, 2), 0])
+            self.e("s_cselect_b64", S_HM[j], [S_OMASK, 0])
             self.e("s_add_u32", S_HB[j][0], [S_HIST[0], S_ENB])
             self.e("s_addc_u32", S_HB[j][1], [S_HIST[1], 0])
 
@@ -533,6 +525,11 @@ class Gen(object):
             self.mov(q[1], 0)
         e("s_mov_b32", S_TAU, [0])
         e("s_mov_b32", S_ACT, [0])
+        e("s_and_b32", T[2], [S_LOHI, 0xffff])
+        e("s_lshr_b32", T[3], [S_LOHI, 16])
+        e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
+        e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
+        e("s_and_b64", S_OMASK, [S(T[4].i, 2), S(T[6].i, 2)])
         if self.hist:
             for j in range(4):
                 e("s_mov_b64", S_HM[j], [0])

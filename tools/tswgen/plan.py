@@ -88,6 +88,8 @@ def build_plan(B, H, W, n_iter, n_wg):
         assert PADF + Q + PADB <= stride
         hdr[g, 0] = Q
         hdr[g, 1] = (3 * ((Q - 1) >> 2) + ((Q - 1) & 3) + n_iter) if Q else -1
+        p0b, lob, hib = bands[g % len(bands)]
+        hdr[g, 2] = (lob - p0b) | ((hib - p0b) << 16)   # owned columns of the workgroup's band
         for q, r in enumerate(rows):
             if r is None:
                 continue

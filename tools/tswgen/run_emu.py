@@ -69,6 +69,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             set64(K.S_OUT, off["out"])
             set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16)
             w.s[K.S_NROWS.i] = tab.shape[1]
+            w.s[K.S_LOHI.i] = int(hdr[wg, 2])
             if hist:
                 set64(K.S_HIST, off["hist"])
                 set64(K.S_HSTRIDE, blur.nbytes)
