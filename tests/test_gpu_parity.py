@@ -266,9 +266,10 @@ def test_asm_plan_table_matches_python_planner():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from tools.tswgen.plan import build_plan
     lib = cspn_amd.load()
-    for B, H, W in ((3, 33, 304), (2, 100, 1216), (1, 7, 256)):
+    for B, H, W in ((3, 33, 304), (2, 100, 1216), (1, 7, 256), (16, 304, 1216)):  # the last one: XCD-aware placement
         n_wg, stride = ctypes.c_int(), ctypes.c_int()
-        lib.cspn_debug_tsw_plan_geo(B, H, W, ctypes.byref(n_wg), ctypes.byref(stride))
+        code = lib.cspn_debug_tsw_plan_geo(B, H, W, ctypes.byref(n_wg), ctypes.byref(stride))
+        xcd = (code & 0xff, (code >> 8) & 0xff, code >> 16) if code else None
         g, h, s = make_inputs(B, H, W, seed=1, sparse=False)
         gd, hd = g.to(DEV), h.to(DEV)
         out = torch.empty_like(hd)
@@ -278,7 +279,7 @@ def test_asm_plan_table_matches_python_planner():
                                          _lib.ALGOS["fused"], ws.data_ptr(), ws_bytes, None)
         assert rc == 0
         torch.cuda.synchronize()
-        hdr_ref, tab_ref = build_plan(B, H, W, 24, n_wg.value)
+        hdr_ref, tab_ref = build_plan(B, H, W, 24, n_wg.value, xcd)
         assert tab_ref.shape[1] == stride.value
         raw = ws.cpu().numpy()
         hdr_bytes = (n_wg.value * 16 + 255) // 256 * 256

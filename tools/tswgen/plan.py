@@ -28,14 +28,28 @@ def plan_bands(W, n_iter):
     return bands
 
 
-def share_segments(B, H, W, n_iter, bands, g, n_wg):
+def wg_group(g, nb, n_wg, xcd=None):
+    """workgroup id -> (group index or None for an idle workgroup, band, number of groups); xcd = (gpx, extra, per_xcd): the
+    XCD-aware placement of cspn2d_tsw.hip (workgroup id -> XCD round robin; a group's workgroups share one XCD's L2)"""
+    if not xcd:
+        return g // nb, g % nb, n_wg // nb
+    gpx, extra, per_xcd = xcd
+    ng = 8 * gpx + extra
+    x, sl = g & 7, g >> 3
+    if sl < gpx * nb:
+        return x * gpx + sl // nb, sl % nb, ng
+    t = (sl - gpx * nb) * 8 + x
+    return (8 * gpx + t // nb if t < extra * nb else None), t % nb, ng
+
+
+def share_segments(B, H, W, n_iter, bands, g, n_wg, xcd=None):
     """Workgroup g = nb * G + band: group G owns a contiguous range of the B*H image rows, its nb workgroups take one band
     each, so the workgroups that read overlapping columns of the same rows run side by side (their halo re-reads hit in
     cache instead of HBM)."""
     nb = len(bands)
-    assert n_wg % nb == 0
-    ng = n_wg // nb
-    G, bi = divmod(g, nb)
+    G, bi, ng = wg_group(g, nb, n_wg, xcd)
+    if G is None:
+        return []
     total = B * H
     r0, r1 = G * total // ng, (G + 1) * total // ng
     segs, r = [], r0
@@ -73,22 +87,22 @@ def plan_geo(B, H, W, n_iter, max_wg, min_rows=16):
         ng += max(1, ng // 8)
 
 
-def build_plan(B, H, W, n_iter, n_wg):
-    """-> (header int32[n_wg][4] = Q, last_step, 0, 0 ; table uint32[n_wg][stride][4])"""
+def build_plan(B, H, W, n_iter, n_wg, xcd=None):
+    """-> (header int32[n_wg][4] = Q, last_step, lo | hi << 16, 0 ; table uint32[n_wg][stride][4])"""
     bands = plan_bands(W, n_iter)
-    assert n_wg % len(bands) == 0
-    stride = stride_of(-(-(B * H) // (n_wg // len(bands))), H, n_iter)
+    ng = wg_group(0, len(bands), n_wg, xcd)[2]
+    stride = stride_of(-(-(B * H) // ng), H, n_iter)
     assert stride <= TAB_MAX_ROWS
     hdr = np.zeros((n_wg, 4), np.int32)
     tab = np.zeros((n_wg, stride, 4), np.uint32)
     for g in range(n_wg):
-        segs = share_segments(B, H, W, n_iter, bands, g, n_wg)
+        segs = share_segments(B, H, W, n_iter, bands, g, n_wg, xcd)
         rows = stream_of(segs)
         Q = len(rows)
         assert PADF + Q + PADB <= stride
         hdr[g, 0] = Q
         hdr[g, 1] = (3 * ((Q - 1) >> 2) + ((Q - 1) & 3) + n_iter) if Q else -1
-        p0b, lob, hib = bands[g % len(bands)]
+        p0b, lob, hib = bands[wg_group(g, len(bands), n_wg, xcd)[1]]
         hdr[g, 2] = (lob - p0b) | ((hib - p0b) << 16)   # owned columns of the workgroup's band
         for q, r in enumerate(rows):
             if r is None:
