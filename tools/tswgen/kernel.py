@@ -266,7 +266,22 @@ class Gen(object):
         pev = (c - 1) % LV if (c - 1) % LV < 4 else None   # the previous step's event slot: its late planes arrive now
         if "noevents" in self.ab:
             ev = pev = None
-        cook = c % 3 == 2 and "nocook" not in self.ab
+        # cooking: the group of four rows that enters from step 3*gamma on is cooked at step 3*gamma - 1 (counter % 3 == 2).
+        # stagger: its last two rows (tasks of waves 4..7) only enter at 3*gamma + 1 / + 2, so those waves cook one step
+        # later: of the two waves that share a SIMD never both cook (and queue their loads) in the same step
+        stag = self.cfg.get("stagger", False)   # measured: 1 % slower than cooking in lock step
+        cook = (c % 3 == 2 or (stag and c % 3 == 0)) and "nocook" not in self.ab
+        cook_hi = stag and c % 3 == 0          # this variant cooks the tasks of waves 4..7
+        g = (((c + 1) // 3) if c % 3 == 2 else (c // 3)) & 1
+
+        def guard():
+            """-> label to jump to for the waves that do not cook in this variant"""
+            if not stag:
+                return None
+            lab = self.p.newlabel("nocook")
+            self.e("s_bitcmp1_b32", (), [S_WV, 2])
+            self.e("s_cbranch_scc0" if cook_hi else "s_cbranch_scc1", (), [lab])
+            return lab
         self.p.label(".LS%d_%%=" % c)
         # ---- top: everything that travels through LDS is requested first
         if "nolds" not in self.ab:
@@ -284,10 +299,11 @@ class Gen(object):
             self.fetch_cook()
         loads = []
         if cook:
-            # normalise + fold the pending task while the boundary rows arrive; its successor's inputs are requested
-            # in small groups between the FMAs of this step (a burst of loads would stall every wave at once)
-            g = ((c + 1) // 3) & 1
+            # normalise + fold the pending task while the boundary rows arrive
+            lab = guard()
             self.cook_pending(V_RINGW[g])
+            if lab:
+                self.p.label(lab)
         self.tail((c - 1) % LV, skip_above1=(ev == 1))
         if ev == 0:  # slot 0's self taps were still needed by the deferred tail
             for k in self.early_planes(0):
@@ -299,12 +315,18 @@ class Gen(object):
             self.take_event()
             self.swap_planes(ev, self.early_planes(ev))
         if cook:
+            lab = guard()
             self.take_cook()
             self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
             loads = self.load_list()
             for i, (dst, voff, base) in enumerate(loads):
-                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"), at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
+                # staggered: the requests go out right here (the other wave of the SIMD keeps the VALU busy meanwhile);
+                # otherwise they are spread between the FMAs of the step
+                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
+                       at=0.0 if stag else self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
+            if lab:
+                self.p.label(lab)
         # received boundary rows
         self.shift(BQ, TA)
         self.push_below(3, BQ, TA, N1[3])
@@ -635,11 +657,19 @@ class Gen(object):
         e("s_cmp_eq_u32", (), [T[1], 0])
         e("s_cselect_b64", S(T[4].i, 2), [-1, 0])
         e("v_cndmask_b32", V_TMP, [V_RINGW[1], V_RINGW[0], S(T[4].i, 2)])
+        l_late = None
+        if self.cfg.get("stagger", False):
+            # waves 4..7 cook one step after the others: their task 0 is cooked by the first step of the loop
+            l_late = self.p.newlabel("late")
+            e("s_bitcmp1_b32", (), [S_WV, 2])
+            e("s_cbranch_scc1", (), [l_late])
         self.cook_pending(V_TMP)
         self.p.waitcnt(lgkm=0)
         self.take_cook()
         self.issue_task(S_CD)
         e("s_add_i32", S_PQ, [S_PQ, 4])
+        if l_late:
+            self.p.label(l_late)
         self.p.waitcnt(lgkm=0)
         e("s_barrier")
         for w in range(NW):
