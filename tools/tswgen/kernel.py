@@ -59,7 +59,7 @@ S_LDSB = S(15)  # LDS base address of the kernel's __shared__ block
 S_NROWS = S(14)  # descriptors in this workgroup's table (<= TAB_MAX_ROWS)
 S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16 (one band per workgroup)
 S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
-S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(32), S(33), S(34), S(35), S(36)
+S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(45), S(33), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
 S_EL, S_ER = S(38, 2), S(40, 2)
 S_ENF = S(44)                   # event: the entering row's descriptor dword 3 (flags)
 S_EO = S(48, 2)                 # event: the retiring row's descriptor dwords 2:3 (boff, flags | lo | hi)
