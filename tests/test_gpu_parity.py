@@ -305,3 +305,20 @@ def test_asm_loop_many_rows_per_group_matches_compiled_kernel():
     n_wg, stride = ctypes.c_int(), ctypes.c_int()
     cspn_amd.load().cspn_debug_tsw_plan_geo(B, H, W, ctypes.byref(n_wg), ctypes.byref(stride))
     assert n_wg.value > 256 and stride.value <= 3072
+
+
+def test_asm_paths_are_deterministic():
+    """an LDS race or a missing wait in the generated loop would show up as run-to-run flicker (tools/stress_asm.py, short)"""
+    B, H, W = 8, 304, 1216
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    g = torch.randn(B, 8, H, W, generator=gen, device=DEV)
+    h = torch.rand(B, 1, H, W, generator=gen, device=DEV) * 80
+    s = (torch.rand(B, 1, H, W, generator=gen, device=DEV) < 0.01).float() * (h + 0.1)
+    go = torch.randn(B, 1, H, W, generator=gen, device=DEV)
+    ref = cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused")
+    gg0, gh0 = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
+    for i in range(12):
+        assert torch.equal(cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused"), ref)
+        if i % 4 == 0:
+            gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
+            assert torch.equal(gg, gg0) and torch.equal(gh, gh0)
