@@ -56,6 +56,28 @@ def test_argument_errors_are_reported_without_gpu():
     assert rc == -2
 
 
+def test_backward_and_aux_argument_errors_are_reported_without_gpu():
+    lib = cspn_amd.load()
+    fake = ctypes.c_void_p(4096)
+    assert lib.cspn2d_backward_workspace_bytes(2, 64, 320, 24) >= (23 + 23) * 2 * 64 * 320 * 4   # two level histories
+    assert lib.cspn2d_backward_workspace_bytes(2, 9, 10, 5) >= (4 + 5) * 2 * 9 * 10 * 4
+    assert lib.cspn2d_backward_workspace_bytes(1, 4, 4, 0) == 0
+    rc = lib.cspn2d_backward_f32(fake, fake, None, None, fake, fake, 1, 4, 4, 3, 0, None, 0, None)
+    assert rc == -1 and b"grad_out" in lib.cspn_last_error()
+    rc = lib.cspn2d_backward_f32(fake, fake, None, fake, fake, fake, 1, 4, 4, 0, 0, None, 0, None)
+    assert rc == -1 and b"n_iter" in lib.cspn_last_error()
+    rc = lib.cspn2d_backward_f32(fake, fake, None, fake, fake, fake, 1, 4, 4, 3, 0, None, 0, None)
+    assert rc == -2 and b"workspace" in lib.cspn_last_error()
+    assert lib.cspn_metrics_workspace_bytes(1000) >= 80
+    rc = lib.cspn_metrics_f32(fake, fake, 1000, fake, None, 0, None)
+    assert rc == -2
+    rc = lib.cspn_metrics_f32(None, fake, 1000, fake, fake, 1 << 20, None)
+    assert rc == -1
+    assert lib.cspn_unpool_f32(fake, fake, 1, 0, 4, 2, None) == -1
+    assert lib.cspn_unpool_backward_f32(None, fake, 1, 4, 4, 2, None) == -1
+    assert lib.cspn_l1_backward_f32(fake, fake, None, fake, fake, 10, None) == -1
+
+
 def test_module_mirrors_reference_interface():
     m = cspn_amd.Affinity_Propagate(24, 3, "8sum")  # positional like torch_resnet_cspn_nyu.py:344-347
     assert m.prop_time == 24 and m.prop_kernel == 3 and m.norm_type == "8sum"
