@@ -41,26 +41,6 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
     }
 }
 
-// The adjoint sweep as a propagation the forward kernel can run (norm_type NONE: gates used as given, centre-sited):
-//   A_t(p) = sum_k w'_k(p - off_k) A_{t+1}(p - off_k) = sum_k' G_k'(p) A_{t+1}(p + off_k'),  k' = 7 - k (off_{7-k} = -off_k),
-//   G_k'(p) = w'_{7-k'}(p + off_k') (0 outside).  gt: [B,8,H,W]
-__global__ __launch_bounds__(256) void transpose_rev_kernel(const float* __restrict__ wf, float* __restrict__ gt, int B, int H,
-                                                             int W) {
-    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int b = (int)(idx / HW);
-    const int r = (int)(idx - (size_t)b * HW);
-    const int y = r / W, x = r - y * W;
-#pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-        const int yy = y + dy2(kp), xx = x + dx2(kp);
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = wf[(size_t)(7 - kp) * total + (size_t)b * HW + (size_t)yy * W + xx];
-        gt[((size_t)b * 8 + kp) * HW + r] = v;
-    }
-}
-
 // A_t(p) = sum_k wt_k(p) A_{t+1}(p - off_k)
 __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__ wt, const float* __restrict__ ain,
                                                         float* __restrict__ aout, int B, int H, int W) {
@@ -172,12 +152,17 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
 
 }  // namespace
 
-static bool asm_path(int B, int H, int W, int n_iter) { return n_iter == 24 && tsw2d_supported(B, H, W); }
+constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
+                                     // one row up and one pixel left of its first row)
+static bool asm_path(int B, int H, int W, int n_iter) {
+    return n_iter == 24 && tsw2d_supported(B, H, W) && 4ull * W + 16 <= FRONT_PAD &&
+           (unsigned long long)B * H * W * 32ull < (1ull << 32);  // 8 coefficient planes of per-lane byte offsets
+}
 
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
-    if (asm_path(B, H, W, n_iter))  // folded 9 + transposed 8 + two 23-level histories + A_0 + a scratch output, then the plan
-        return (size_t)(9 + 8 + 23 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
+    if (asm_path(B, H, W, n_iter))  // folded 9 + two 23-level histories + A_0 + a scratch output, then the plan
+        return FRONT_PAD + (size_t)(9 + 23 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
@@ -187,9 +172,10 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
     float* wf = (float*)ws;
     if (asm_path(B, H, W, n_iter)) {
         // both sweeps run in the fused ring kernel (cspn2d_tsw.hip), each writing its 23 intermediate levels: the forward
-        // as it is, the adjoint as a norm_type-NONE propagation over transposed coefficients
-        float* gt = wf + 9 * total;
-        float* hh = gt + 8 * total;
+        // as it is, the adjoint as a propagation whose coefficients are the folded planes read neighbour-sited with the
+        // channel order reversed (generator option adj)
+        wf = (float*)((char*)ws + FRONT_PAD);
+        float* hh = wf + 9 * total;
         float* ah = hh + 23 * total;
         float* a0 = ah + 23 * total;
         float* scratch = a0 + total;
@@ -198,9 +184,8 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
         if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, plan, st, hh)) return e;
         hipLaunchKernelGGL(fold2d_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, wf, B, H, W, norm);
-        hipLaunchKernelGGL(transpose_rev_kernel, dim3(blocks), dim3(256), 0, st, wf, gt, B, H, W);
-        if (int e = check_launch("transpose_rev_kernel")) return e;
-        if (int e = tsw2d_pass(gt, gout, gout, nullptr, a0, B, H, W, CSPN_NORM_NONE, plan, st, ah)) return e;
+        if (int e = check_launch("fold2d_kernel")) return e;
+        if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, plan, st, ah)) return e;
         if (gg && norm != CSPN_NORM_NONE) {
             hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
             if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }

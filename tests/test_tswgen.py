@@ -39,6 +39,56 @@ def test_emulated_history_variant_writes_every_level():
     assert nanmis == 0 and err <= 1e-4
 
 
+def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
+    """cfg adj: the backward's adjoint sweep A_t(p) = sum_k w'_k(p - off_k) A_{t+1}(p - off_k) run by the ring kernel over the
+    folded planes (neighbour-sited, channel order reversed), every level checked"""
+    from tools.tswgen.emu import Emu
+    from tools.tswgen.plan import build_plan, plan_bands
+    from oracle.backward import _shift, DY, DX
+    B, H, W, n_wg = 2, 13, 304, 4
+    rng = np.random.default_rng(1)
+    total = B * H * W
+    wp = (rng.standard_normal((8, B, H, W)) * 0.3).astype(np.float32)
+    a = rng.standard_normal((B, H, W)).astype(np.float32)
+    levels, cur = [], a.copy()
+    for _ in range(24):
+        nxt = np.zeros_like(cur)
+        for k in range(8):
+            nxt += _shift(wp[k] * cur, -DY[k], -DX[k])
+        cur = nxt.astype(np.float32)
+        levels.append(cur)
+    prog = K.build(dict(norm=2, adj=True, hist=True))
+    assert not check_hazards(prog)
+    n_wg = -(-n_wg // len(plan_bands(W, 24))) * len(plan_bands(W, 24))
+    hdr, tab = build_plan(B, H, W, 24, n_wg)
+    bufs = {"gd": wp, "blur": a, "out": np.zeros(total, np.float32), "plan": tab, "hist": np.full(23 * total, np.nan, np.float32)}
+    off, end = {}, 8192 + 65536   # the variant reads up to 4*W + 16 bytes in front of the planes
+    for n, arr in bufs.items():
+        off[n] = end
+        end += (arr.nbytes + 4095) // 4096 * 4096 + 12288
+    mem = np.zeros(end, np.uint8)
+    mem.view(np.float32)[:] = np.nan
+    for n, arr in bufs.items():
+        mem[off[n]:off[n] + arr.nbytes] = arr.view(np.uint8).ravel()
+    for wg in range(n_wg):
+        if hdr[wg, 0] == 0:
+            continue
+        emu = Emu(prog, mem, K.LDS_BYTES)
+        for w in emu.waves:
+            w.v[0] = np.arange(64, dtype=np.uint32)
+            for r, v in ((K.S_GD, off["gd"]), (K.S_BLUR, off["blur"]), (K.S_HIN, 4096), (K.S_SP, 4096), (K.S_OUT, off["out"]),
+                         (K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16), (K.S_HIST, off["hist"]), (K.S_HSTRIDE, total * 4)):
+                w.s[r.i], w.s[r.i + 1] = v & 0xffffffff, v >> 32
+            w.s[K.S_W4.i], w.s[K.S_HW4.i], w.s[K.S_LAST.i], w.s[K.S_WV.i] = 4 * W, 4 * total, int(hdr[wg, 1]), w.wid
+            w.s[K.S_NROWS.i], w.s[K.S_LOHI.i] = tab.shape[1], int(hdr[wg, 2])
+        emu.run()
+    out = mem[off["out"]:off["out"] + total * 4].view(np.float32).reshape(B, H, W)
+    hb = mem[off["hist"]:off["hist"] + 23 * total * 4].view(np.float32).reshape(23, B, H, W // 4, 4)[..., [0, 2, 1, 3]].reshape(23, B, H, W)
+    assert np.abs(out - levels[23]).max() <= 1e-5 * np.abs(levels[23]).max()
+    for n in range(1, 24):
+        assert np.abs(hb[n - 1] - levels[n - 1]).max() <= 1e-5 * np.abs(levels[n - 1]).max(), n
+
+
 def test_generated_include_is_current_and_hazard_free():
     inc = open(os.path.join(ROOT, "cspn_amd", "csrc", "cspn2d_tsw_gen.inc")).read()
     for norm, sparse, hin in ((0, 0, 0), (1, 1, 1), (2, 1, 0)):
@@ -48,6 +98,8 @@ def test_generated_include_is_current_and_hazard_free():
     p = K.build(dict(norm=2, sparse=False, hin=False, hist=True))
     assert not check_hazards(p)
     assert ("#define TSW_ASM_HIST_2_0 R\"ASM(\n%s\n)ASM\"" % p.text()) in inc
+    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True, adj=True))
+    assert ("#define TSW_ASM_ADJ R\"ASM(\n%s\n)ASM\"" % p.text()) in inc
 
 
 def test_scheduler_respects_hazards_and_emulator_flags_misuse():

@@ -81,6 +81,13 @@ class Gen(object):
         self.p = Prog()
         self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
         self.hist = cfg.get("hist", False)
+        # adj: the adjoint sweep of the backward pass as a propagation.  Coefficients come from the folded planes w'
+        # ([8][B*H*W], what fold2d_kernel writes) read neighbour-sited with the channel order reversed --
+        # G_k(p) = w'_{7-k}(p + off_k), since off_{7-k} = -off_k -- and are used as they are (no normalisation, c' = 0)
+        self.adj = cfg.get("adj", False)
+        if self.adj:
+            assert self.norm == 2 and not self.sparse and not self.hin
+        self.sited = self.norm != 2 or self.adj   # guidance plane k is read at (y + dy_k, x + dx_k)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
@@ -384,7 +391,7 @@ class Gen(object):
         self.e("s_cbranch_scc1", (), [l_math])
         self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_ACTIVE])
         self.e("s_cbranch_scc0", (), [l_inact])
-        if norm != 2:
+        if self.sited:
             # rows above / below the image were read from whatever lies there in the tensor (always inside it: the planes
             # read at dy = -1 are channels 5..7, those at dy = +1 channels 0..2): they count as zero
             for flag, chans in ((F_UP, (0, 1, 2)), (F_DN, (5, 6, 7))):
@@ -485,8 +492,17 @@ class Gen(object):
         issued between the FMAs of the step).  No clamping: a row above / below the image, or the all-zero descriptor of
         an inactive row, still addresses memory inside the tensors (see cook_pending)."""
         self.e("s_mov_b32", S_PFLAGS, [cd[3]])
-        self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[0]])
-        self.e("s_addc_u32", GB_MID[1], [S_GD[1], cd[1]])
+        if self.adj:   # planar coefficient planes: a row starts where it starts in a 1-channel tensor.  Plane 0 is read
+            # one row up and one pixel left: the base is biased by W4 + 16 bytes (and the lane offsets by the same) so that
+            # every lane offset stays non-negative; the caller keeps that much addressable memory in front of the planes
+            self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[2]])
+            self.e("s_addc_u32", GB_MID[1], [S_GD[1], 0])
+            self.e("s_add_i32", T[6], [S_W4, 16])
+            self.e("s_sub_u32", GB_MID[0], [GB_MID[0], T[6]])
+            self.e("s_subb_u32", GB_MID[1], [GB_MID[1], 0])
+        else:
+            self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[0]])
+            self.e("s_addc_u32", GB_MID[1], [S_GD[1], cd[1]])
         self.e("s_add_u32", B_BLUR[0], [S_BLUR[0], cd[2]])
         self.e("s_addc_u32", B_BLUR[1], [S_BLUR[1], 0])
         if self.hin:
@@ -605,14 +621,17 @@ class Gen(object):
         e("s_lshl_b32", T[3], [T[1], 9])
         e("v_add_u32", V_OFF1, [T[3], V_OFF1])
         for k in range(8):
-            e("s_mul_i32", T[3], [S_HW4, k])
-            if self.norm != 2:
+            e("s_mul_i32", T[3], [S_HW4, (7 - k) if self.adj else k])   # S_HW4: bytes from one guidance plane to the next
+            if self.sited:
                 if DY[k] > 0:
                     e("s_add_i32", T[3], [T[3], S_W4])
                 if DY[k] < 0:
                     e("s_sub_i32", T[3], [T[3], S_W4])
                 if DX[k] != 0 and "aligned2" not in self.ab:
                     e("s_add_i32", T[3], [T[3], 4 * DX[k]])
+            if self.adj:
+                e("s_add_i32", T[3], [T[3], S_W4])
+                e("s_add_i32", T[3], [T[3], 16])
             e("v_add_u32", V_OFFK[k], [T[3], V_OFF1])
         # constant edge-lane masks
         e("s_cmp_eq_u32", (), [T[1], 0])
