@@ -135,6 +135,12 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
     }
     if (gb) gb[idx] = a0 + dC * (om * (1.f - sigma) + m);
     if (gg) {
+        // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ys = y - dy2(k), xs = x - dx2(k);
+            if (ys < 0 || ys >= H || xs < 0 || xs >= W) gg[(size_t)b * 8 * HW + k * HW + r] = 0.f;
+        }
         const float t2 = T1 / (S * S);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -161,8 +167,8 @@ static bool asm_path(int B, int H, int W, int n_iter) {
 
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
-    if (asm_path(B, H, W, n_iter))  // folded 9 + two 23-level histories + A_0 + a scratch output, then the plan
-        return FRONT_PAD + (size_t)(9 + 23 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
+    if (asm_path(B, H, W, n_iter))  // forward levels 23 + folded coefficients 8 + adjoint levels 23 + A_0 + a scratch output, plan
+        return FRONT_PAD + (size_t)(23 + 8 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
@@ -174,22 +180,17 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         // both sweeps run in the fused ring kernel (cspn2d_tsw.hip), each writing its 23 intermediate levels: the forward
         // as it is, the adjoint as a propagation whose coefficients are the folded planes read neighbour-sited with the
         // channel order reversed (generator option adj)
-        wf = (float*)((char*)ws + FRONT_PAD);
-        float* hh = wf + 9 * total;
-        float* ah = hh + 23 * total;
+        // the forward sweep also leaves the 8 folded coefficient planes right behind its 23 level planes
+        float* hh = (float*)((char*)ws + FRONT_PAD);
+        wf = hh + 23 * total;
+        float* ah = wf + 8 * total;
         float* a0 = ah + 23 * total;
         float* scratch = a0 + total;
         void* plan = (void*)(((uintptr_t)(scratch + total) + 255) & ~(uintptr_t)255);
         const unsigned blocks = (unsigned)((total + 255) / 256);
         if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
         if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, plan, st, hh)) return e;
-        hipLaunchKernelGGL(fold2d_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, wf, B, H, W, norm);
-        if (int e = check_launch("fold2d_kernel")) return e;
         if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, plan, st, ah)) return e;
-        if (gg && norm != CSPN_NORM_NONE) {
-            hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
-            if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-        }
         hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
                            H, W, n_iter, norm);
         return check_launch("bwd_final_kernel");
@@ -208,10 +209,6 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         hipLaunchKernelGGL(bwd_step_kernel, dim3(blocks), dim3(256), 0, st, wt,
                            t == n_iter - 1 ? gout : ah + (size_t)(t + 1) * total, ah + (size_t)t * total, B, H, W);
     if (int e = check_launch("bwd_step_kernel")) return e;
-    if (gg && norm != CSPN_NORM_NONE) {
-        hipError_t e = hipMemsetAsync(gg, 0, total * 8 * sizeof(float), st);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    }
     hipLaunchKernelGGL(bwd_final_kernel<false>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, nullptr, gout, gg, gb, B,
                        H, W, n_iter, norm);
     return check_launch("bwd_final_kernel");

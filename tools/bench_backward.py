@@ -44,7 +44,7 @@ def main():
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
                       "note": "forward and adjoint sweeps each as one launch of the fused ring kernel writing its 23 intermediate "
-                              "levels, + fold and final pass; workspace 57 planes + the row-descriptor table"}))
+                              "levels (the forward one also the folded coefficients), + the final pass; workspace 56 planes + the row-descriptor table"}))
 
 
 if __name__ == "__main__":

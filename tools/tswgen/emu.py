@@ -293,6 +293,8 @@ class Emu(object):
             a, b = rs(w, s[0]), rs(w, s[1]) + w.scc
             self.ws(w, d[0], a - b)
             w.scc = int(b > a)
+        elif o == "s_mul_hi_u32":
+            self.ws(w, d[0], (rs(w, s[0]) * rs(w, s[1])) >> 32)
         elif o == "s_mul_i32":
             self.ws(w, d[0], i32(rs(w, s[0])) * i32(rs(w, s[1])))
         elif o == "s_lshl_b32":

@@ -70,6 +70,9 @@ S_HIST, S_HSTRIDE = S(92, 2), S(94, 2)       # inputs: base of the level-1 plane
 S_ENB = S(46)                                   # entering row's descriptor dword 2 (byte offset in a 1-channel tensor)
 S_HB = [S(84, 2), S(86, 2), S(88, 2), S(90, 2)]     # per slot: where the row's next level goes
 S_HM = [S(0, 2), S(4, 2), S(96, 2), S(98, 2)]       # per slot: lanes that own columns of the row (0: halo / inactive row)
+S_WF = S(50, 2)     # history mode: the 8 folded coefficient planes w'_k ([8][B*H*W], right behind the 23 level planes)
+S_PBOFF = S(47)     # history mode: byte offset (1-channel tensor) of the pending task's row
+S_CMASK = S(52, 2)  # history mode: cooking lanes (2 pixels each) whose pixels lie in the band's owned columns
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
 S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
 GB_MID, B_BLUR, B_HIN, B_SP = S(2, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task (s0:1, s4:5: S_HM)
@@ -475,6 +478,22 @@ class Gen(object):
                 self.e("v_pk_mul_f32", g[k], [g[k], scale])
             if not nw:
                 self.e("ds_write_b64", (), [ringw, g[k]], offset=k * 1024)
+        if self.hist and not self.adj:
+            # the folded coefficients are also what the backward's adjoint sweep propagates with: keep a copy of the rows
+            # and columns this workgroup owns (planar, [8][B*H*W])
+            l_nown = self.p.newlabel("nown")
+            self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_OWNED])
+            self.e("s_cbranch_scc0", (), [l_nown])
+            self.e("s_add_u32", T[8], [S_WF[0], S_PBOFF])
+            self.e("s_addc_u32", T[9], [S_WF[1], 0])
+            self.e("s_mov_b64", EXEC, [S_CMASK])
+            for k in range(8):
+                self.e("global_store_dwordx2", (), [V_OFF1, g[k], S(T[8].i, 2)])
+                if k < 7:
+                    self.e("s_add_u32", T[8], [T[8], S_HSTRIDE[0]])
+                    self.e("s_addc_u32", T[9], [T[9], S_HSTRIDE[1]])
+            self.e("s_mov_b64", EXEC, [-1])
+            self.p.label(l_nown)
         hv = PEND_HIN if self.hin else PEND_BLUR
         if not nw:
             self.e("ds_write_b64", (), [ringw, cc], offset=8 * 1024)
@@ -492,6 +511,8 @@ class Gen(object):
         issued between the FMAs of the step).  No clamping: a row above / below the image, or the all-zero descriptor of
         an inactive row, still addresses memory inside the tensors (see cook_pending)."""
         self.e("s_mov_b32", S_PFLAGS, [cd[3]])
+        if self.hist and not self.adj:
+            self.e("s_mov_b32", S_PBOFF, [cd[2]])
         if self.adj:   # planar coefficient planes: a row starts where it starts in a 1-channel tensor.  Plane 0 is read
             # one row up and one pixel left: the base is biased by W4 + 16 bytes (and the lane offsets by the same) so that
             # every lane offset stays non-negative; the caller keeps that much addressable memory in front of the planes
@@ -572,6 +593,13 @@ class Gen(object):
             for j in range(4):
                 e("s_mov_b64", S_HM[j], [0])
                 e("s_mov_b64", S_HB[j], [S_HIST])
+            # cooking lanes inside the owned columns: 4*xb (V_OFF1, set below) against 4*lo, 4*hi -- computed after V_OFF1
+            e("s_mul_i32", T[2], [S_HSTRIDE[0], 23])
+            e("s_mul_hi_u32", T[3], [S_HSTRIDE[0], 23])
+            e("s_mul_i32", T[4], [S_HSTRIDE[1], 23])
+            e("s_add_i32", T[3], [T[3], T[4]])
+            e("s_add_u32", S_WF[0], [S_HIST[0], T[2]])
+            e("s_addc_u32", S_WF[1], [S_HIST[1], T[3]])
         e("s_and_b32", T[1], [S_WV, 1])            # T1 = wave parity (= cooking half)
         e("s_lshr_b32", T[2], [S_WV, 1])           # T2 = wv >> 1
         # boundary exchange addresses
@@ -633,6 +661,14 @@ class Gen(object):
                 e("s_add_i32", T[3], [T[3], S_W4])
                 e("s_add_i32", T[3], [T[3], 16])
             e("v_add_u32", V_OFFK[k], [T[3], V_OFF1])
+        if self.hist:
+            e("s_and_b32", T[2], [S_LOHI, 0xffff])
+            e("s_lshl_b32", T[2], [T[2], 2])
+            e("s_lshr_b32", T[3], [S_LOHI, 16])
+            e("s_lshl_b32", T[3], [T[3], 2])
+            e("v_cmp_ge_u32", S(T[4].i, 2), [V_OFF1, T[2]])
+            e("v_cmp_lt_u32", S(T[6].i, 2), [V_OFF1, T[3]])
+            e("s_and_b64", S_CMASK, [S(T[4].i, 2), S(T[6].i, 2)])
         # constant edge-lane masks
         e("s_cmp_eq_u32", (), [T[1], 0])
         e("s_cselect_b32", S_ELC[0], [1, 0])

@@ -30,7 +30,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
     prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist), sched=sched)
-    histbuf = np.full((23, B, 1, H, W), np.nan, np.float32) if hist else None
+    histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
     nb = len(plan_bands(W, n_iter))
     n_wg = -(-n_wg // nb) * nb   # whole groups of nb workgroups
@@ -89,7 +89,11 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none"][norm])
     if hist:
         assert not hin
-        hb = mem[off["hist"]:off["hist"] + histbuf.nbytes].view(np.float32).reshape(23, B, H, W // 4, 4)
+        wfb = mem[off["hist"] + 23 * blur.nbytes:off["hist"] + 31 * blur.nbytes].view(np.float32).reshape(8, B, H, W)
+        wf_ref = folded_planes(g, sp, norm)
+        assert np.array_equal(np.isnan(wfb), np.isnan(wf_ref))
+        assert np.nanmax(np.abs(wfb - wf_ref)) <= 1e-6 * max(1.0, np.nanmax(np.abs(wf_ref))), "folded coefficient planes"
+        hb = mem[off["hist"]:off["hist"] + 23 * blur.nbytes].view(np.float32).reshape(23, B, H, W // 4, 4)
         hb = hb[..., [0, 2, 1, 3]].reshape(23, B, 1, H, W)   # stored in register order (c0,c2,c1,c3) per 4-column group
         worst = 0.0
         for lv in range(1, 24):
@@ -113,6 +117,25 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         print("   per wave-step: VALU %.1f SALU %.1f nop %.1f mem %.1f (steps %d)" % (
             nv / 8 / steps / n_wg, ns / 8 / steps / n_wg, nn / 8 / steps / n_wg, nm / 8 / steps / n_wg, steps))
     return err, nanmis.sum(), out, ref
+
+
+def folded_planes(g, sp, norm):
+    """w'_k(p) = (1 - m) G_k / sum|G| (reference cspn.py:85-144 + the mask of :81), planar [8][B,H,W]"""
+    B, _, H, W = g.shape
+    gp = np.abs(g) if norm == 1 else g
+    G = np.zeros((8, B, H, W), np.float32)
+    for k in range(8):
+        if norm == 2:
+            G[k] = gp[:, k]
+        else:
+            pad = np.zeros((B, H + 2, W + 2), np.float32)
+            pad[:, 1:-1, 1:-1] = gp[:, k]
+            G[k] = pad[:, 1 + K.DY[k]:1 + K.DY[k] + H, 1 + K.DX[k]:1 + K.DX[k] + W]
+    with np.errstate(all="ignore"):
+        w = G if norm == 2 else G / np.abs(G).sum(0, keepdims=True)
+        if sp is not None:
+            w = (1 - np.sign(sp[:, 0]))[None] * w
+    return w.astype(np.float32)
 
 
 def ref_hin(g, blur, sp, hin, n_iter, norm):
