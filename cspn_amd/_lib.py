@@ -56,6 +56,14 @@ def load():
     lib.cspn2d_backward_workspace_bytes.argtypes = [c_int] * 4
     lib.cspn2d_backward_f32.restype = c_int
     lib.cspn2d_backward_f32.argtypes = [vp] * 6 + [c_int] * 5 + [vp, c_size_t, vp]
+    lib.cspn2d_history_bytes.restype = c_size_t
+    lib.cspn2d_history_bytes.argtypes = [c_int] * 4
+    lib.cspn2d_forward_history_f32.restype = c_int
+    lib.cspn2d_forward_history_f32.argtypes = [vp] * 5 + [c_size_t] + [c_int] * 5 + [vp, c_size_t, vp]
+    lib.cspn2d_backward_history_workspace_bytes.restype = c_size_t
+    lib.cspn2d_backward_history_workspace_bytes.argtypes = [c_int] * 4
+    lib.cspn2d_backward_history_f32.restype = c_int
+    lib.cspn2d_backward_history_f32.argtypes = [vp] * 5 + [c_size_t, vp, vp] + [c_int] * 5 + [vp, c_size_t, vp]
     lib.cspn_metrics_workspace_bytes.restype = c_size_t
     lib.cspn_metrics_workspace_bytes.argtypes = [c_size_t]
     lib.cspn_metrics_f32.restype = c_int

@@ -24,17 +24,30 @@ from . import functional as F
 
 class _CSPN2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, guidance, blur_depth, sparse_depth, n_iter, norm_type, algo):
-        ctx.save_for_backward(guidance, blur_depth, sparse_depth)
+    def forward(ctx, guidance, blur_depth, sparse_depth, n_iter, norm_type, algo, keep_history):
         ctx.n_iter, ctx.norm_type = n_iter, norm_type
+        needs_grad = guidance.requires_grad or blur_depth.requires_grad
+        B, _, H, W = guidance.shape
+        if (keep_history and needs_grad and algo in ("auto", "fused") and guidance.is_cuda
+                and F.cspn2d_history_bytes(B, H, W, n_iter) > 0):
+            # training: the forward keeps every intermediate level and the folded coefficients (as autograd would keep
+            # the reference's temporaries), the backward starts from them instead of recomputing
+            out, hist = F.cspn2d_forward_with_history(guidance, blur_depth, sparse_depth, n_iter, norm_type)
+            ctx.save_for_backward(guidance, blur_depth, sparse_depth, hist)
+            return out
+        ctx.save_for_backward(guidance, blur_depth, sparse_depth, None)
         return F.cspn2d_forward(guidance, blur_depth, sparse_depth, n_iter, norm_type, algo)
 
     @staticmethod
     def backward(ctx, grad_out):
-        guidance, blur_depth, sparse_depth = ctx.saved_tensors
-        gg, gh = F.cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, ctx.n_iter, ctx.norm_type,
-                                   need_guidance=ctx.needs_input_grad[0], need_blur=ctx.needs_input_grad[1])
-        return gg, gh, None, None, None, None
+        guidance, blur_depth, sparse_depth, hist = ctx.saved_tensors
+        if hist is not None:
+            gg, gh = F.cspn2d_backward_from_history(guidance, blur_depth, sparse_depth, grad_out, hist, ctx.n_iter, ctx.norm_type,
+                                                    need_guidance=ctx.needs_input_grad[0], need_blur=ctx.needs_input_grad[1])
+        else:
+            gg, gh = F.cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, ctx.n_iter, ctx.norm_type,
+                                       need_guidance=ctx.needs_input_grad[0], need_blur=ctx.needs_input_grad[1])
+        return gg, gh, None, None, None, None, None
 
 
 class Affinity_Propagate(nn.Module):
@@ -49,6 +62,7 @@ class Affinity_Propagate(nn.Module):
         self.in_feature = 1
         self.out_feature = 1
         self.algo = "auto"
+        self.keep_history = True   # training: keep the forward's level history for the backward
 
     def forward(self, guidance, blur_depth, sparse_depth=None, n_iter=None):
         n = self.prop_time if n_iter is None else int(n_iter)
@@ -56,7 +70,7 @@ class Affinity_Propagate(nn.Module):
             raise ValueError('unknown norm %s' % self.norm_type)
         if n == 0:
             return blur_depth  # cspn.py:61,66,83: the very same tensor object
-        return _CSPN2dFunction.apply(guidance, blur_depth, sparse_depth, n, self.norm_type, self.algo)
+        return _CSPN2dFunction.apply(guidance, blur_depth, sparse_depth, n, self.norm_type, self.algo, self.keep_history)
 
     def extra_repr(self):
         return "prop_time=%d, prop_kernel=%d, norm_type=%r" % (self.prop_time, self.prop_kernel, self.norm_type)

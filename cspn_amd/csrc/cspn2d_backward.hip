@@ -214,4 +214,36 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
     return check_launch("bwd_final_kernel");
 }
 
+// ---- training mode: the forward keeps its level history, the backward starts from it ------------------------------------
+// history = [FRONT_PAD bytes][H_1 .. H_23][w'_0 .. w'_7] (what the forward sweep of backward2d leaves behind)
+size_t history2d_bytes(int B, int H, int W, int n_iter) {
+    return asm_path(B, H, W, n_iter) ? FRONT_PAD + (size_t)(23 + 8) * B * H * W * sizeof(float) : 0;
+}
+
+int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
+                      int norm, void* ws, hipStream_t st) {
+    float* hh = (float*)((char*)history + FRONT_PAD);
+    if (int e = tsw2d_build_plan(B, H, W, ws, st)) return e;
+    return tsw2d_pass(g, blur, blur, sparse, out, B, H, W, norm, ws, st, hh);
+}
+
+size_t backward2d_history_workspace(int B, int H, int W) {
+    return (size_t)(23 + 1) * B * H * W * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
+}
+
+int backward2d_history(const float* g, const float* blur, const float* sparse, const float* gout, const void* history, float* gg,
+                       float* gb, int B, int H, int W, int norm, void* ws, hipStream_t st) {
+    const size_t total = (size_t)B * H * W;
+    const float* hh = (const float*)((const char*)history + FRONT_PAD);
+    const float* wf = hh + 23 * total;
+    float* ah = (float*)ws;
+    float* a0 = ah + 23 * total;
+    void* plan = (void*)(((uintptr_t)(a0 + total) + 255) & ~(uintptr_t)255);
+    if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
+    if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, plan, st, ah)) return e;
+    hipLaunchKernelGGL(bwd_final_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
+                       gout, gg, gb, B, H, W, 24, norm);
+    return check_launch("bwd_final_kernel");
+}
+
 }  // namespace cspn

@@ -111,6 +111,42 @@ int cspn2d_backward_f32(const float* guidance, const float* blur, const float* s
     return backward2d(guidance, blur, sparse, grad_out, grad_guidance, grad_blur, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream);
 }
 
+size_t cspn2d_history_bytes(int B, int H, int W, int n_iter) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return history2d_bytes(B, H, W, n_iter);
+}
+
+int cspn2d_forward_history_f32(const float* guidance, const float* blur, const float* sparse, float* out, void* history,
+                               size_t history_bytes, int B, int H, int W, int n_iter, int norm_type, void* ws, size_t ws_bytes,
+                               cspn_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d H=%d W=%d", B, H, W); return CSPN_E_BADARG; }
+    const size_t hb = history2d_bytes(B, H, W, n_iter);
+    if (hb == 0) { set_error("no history mode for B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
+    if (!history || history_bytes < hb || ((uintptr_t)history & 255u)) { set_error("history buffer too small or misaligned: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
+    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, fused2d_workspace(B, H, W, n_iter))) return e;
+    if (((uintptr_t)out & 15u) != 0) { set_error("output must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
+    return forward2d_history(guidance, blur, sparse, out, history, B, H, W, norm_type, ws, (hipStream_t)stream);
+}
+
+size_t cspn2d_backward_history_workspace_bytes(int B, int H, int W, int n_iter) {
+    if (B <= 0 || H <= 0 || W <= 0 || history2d_bytes(B, H, W, n_iter) == 0) return 0;
+    return backward2d_history_workspace(B, H, W);
+}
+
+int cspn2d_backward_history_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
+                                const void* history, size_t history_bytes, float* grad_guidance, float* grad_blur, int B, int H,
+                                int W, int n_iter, int norm_type, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d H=%d W=%d", B, H, W); return CSPN_E_BADARG; }
+    const size_t hb = history2d_bytes(B, H, W, n_iter);
+    if (hb == 0) { set_error("no history mode for B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
+    if (!grad_out) { set_error("null grad_out"); return CSPN_E_BADARG; }
+    if (!history || history_bytes < hb) { set_error("history buffer too small: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
+    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_history_workspace(B, H, W))) return e;
+    if (!grad_guidance && !grad_blur) return 0;
+    return backward2d_history(guidance, blur, sparse, grad_out, history, grad_guidance, grad_blur, B, H, W, norm_type, ws,
+                              (hipStream_t)stream);
+}
+
 size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     return stepwise3d_workspace(B, D, H, W, n_iter);

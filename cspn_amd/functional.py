@@ -78,6 +78,59 @@ def cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, nor
     return gg, gh
 
 
+def cspn2d_history_bytes(B, H, W, n_iter):
+    """bytes of the level history the training-mode forward keeps for its backward (0: not available for this shape)"""
+    return int(_lib.load().cspn2d_history_bytes(int(B), int(H), int(W), int(n_iter)))
+
+
+def cspn2d_forward_with_history(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum"):
+    """Training-mode forward: same output as cspn2d_forward, plus an opaque `history` tensor (every intermediate level and
+    the folded coefficients) for cspn2d_backward_from_history.  Only where cspn2d_history_bytes(...) > 0."""
+    lib = _lib.load()
+    B, _, H, W = guidance.shape
+    g = _prep(guidance, "guidance", (B, 8, H, W))
+    h = _prep(blur_depth, "blur_depth", (B, 1, H, W))
+    s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
+    out = torch.empty_like(h)
+    with torch.cuda.device(g.device):
+        hb = lib.cspn2d_history_bytes(B, H, W, int(n_iter))
+        if hb == 0:
+            raise _lib.CspnError("cspn_amd: no history mode for shape %s, n_iter %d" % (tuple(guidance.shape), n_iter))
+        hist = torch.empty(hb, dtype=torch.uint8, device=g.device)
+        ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        rc = lib.cspn2d_forward_history_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                            hist.data_ptr(), hb, B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                            ws.data_ptr(), ws_bytes, torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn2d_forward_history_f32")
+    return out, hist
+
+
+def cspn2d_backward_from_history(guidance, blur_depth, sparse_depth, grad_out, history, n_iter=24, norm_type="8sum",
+                                 need_guidance=True, need_blur=True):
+    """Gradients as cspn2d_backward, starting from the history a training-mode forward kept."""
+    lib = _lib.load()
+    B, _, H, W = guidance.shape
+    g = _prep(guidance, "guidance", (B, 8, H, W))
+    h = _prep(blur_depth, "blur_depth", (B, 1, H, W))
+    s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
+    go = _prep(grad_out, "grad_out", (B, 1, H, W))
+    gg = torch.empty_like(g) if need_guidance else None
+    gh = torch.empty_like(h) if need_blur else None
+    if not (need_guidance or need_blur):
+        return gg, gh
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn2d_backward_history_workspace_bytes(B, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        rc = lib.cspn2d_backward_history_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, go.data_ptr(),
+                                             history.data_ptr(), history.numel(), gg.data_ptr() if gg is not None else None,
+                                             gh.data_ptr() if gh is not None else None, B, H, W, int(n_iter),
+                                             _lib.NORM_TYPES[norm_type], ws.data_ptr(), ws_bytes,
+                                             torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn2d_backward_history_f32")
+    return gg, gh
+
+
 def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
     """gate [B,26,D,H,W], feat [B,1,D,H,W] -> [B,1,D,H,W]; n_iter fused 3x3x3 propagation steps."""
     lib = _lib.load()

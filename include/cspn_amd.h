@@ -84,6 +84,23 @@ int cspn2d_backward_f32(const float* guidance, const float* blur, const float* s
                         float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
+/* Training mode (optional, faster): the forward also keeps what the backward needs -- every intermediate level H_1..H_23 and
+ * the folded coefficients, cspn2d_history_bytes() bytes, 256-B aligned; 0 = not available for this shape / n_iter (then use
+ * cspn2d_forward_f32 + cspn2d_backward_f32, which recomputes the history).  This is what torch autograd does for the
+ * reference by saving ~27 temporaries per iteration.
+ *   cspn2d_forward_history_f32: same result as cspn2d_forward_f32, plus `history`; workspace cspn2d_workspace_bytes().
+ *   cspn2d_backward_history_f32: same result as cspn2d_backward_f32 from that history; workspace
+ *   cspn2d_backward_history_workspace_bytes(). */
+size_t cspn2d_history_bytes(int B, int H, int W, int n_iter);
+int cspn2d_forward_history_f32(const float* guidance, const float* blur, const float* sparse, float* out, void* history,
+                               size_t history_bytes, int B, int H, int W, int n_iter, int norm_type,
+                               void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+size_t cspn2d_backward_history_workspace_bytes(int B, int H, int W, int n_iter);
+int cspn2d_backward_history_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
+                                const void* history, size_t history_bytes, float* grad_guidance, float* grad_blur,
+                                int B, int H, int W, int n_iter, int norm_type,
+                                void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
 /* ---- 3D: replaces n_iter chained fluid.layers.affinity_propagate calls,
  * reference cspn_paddle/demo.py:41-43,50-52 (kernel_size == 3 only, demo.py:90)
  *   gate [B,26,D,H,W], feat [B,1,D,H,W], sparse [B,1,D,H,W] or NULL, out [B,1,D,H,W] */

@@ -72,6 +72,35 @@ def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("norm,sp", [("8sum", True), ("8sum_abs", False)])
+def test_training_mode_history_matches_recompute_path(norm, sp):
+    """the forward that keeps its level history + the backward that starts from it == plain forward + recomputing backward"""
+    import cspn_amd
+    B, H, W, N = 3, 70, 512, 24
+    assert cspn_amd.cspn2d_history_bytes(B, H, W, N) > 0 and cspn_amd.cspn2d_history_bytes(B, H, 64, N) == 0
+    g, h, s = make_inputs(B, H, W, seed=21, sparse=sp, neg=sp)
+    go = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(6)).cuda()
+    gd, hd, sd = g.cuda(), h.cuda(), None if s is None else s.cuda()
+    out_ref = cspn_amd.cspn2d_forward(gd, hd, sd, N, norm)
+    gg_ref, gh_ref = cspn_amd.cspn2d_backward(gd, hd, sd, go, N, norm)
+    out, hist = cspn_amd.cspn2d_forward_with_history(gd, hd, sd, N, norm)
+    gg, gh = cspn_amd.cspn2d_backward_from_history(gd, hd, sd, go, hist, N, norm)
+    assert torch.equal(out, out_ref) and torch.equal(gg, gg_ref) and torch.equal(gh, gh_ref)
+    # through the module: training keeps the history, and the gradients agree with the oracle
+    _, rgg, rgh = cspn2d_backward_oracle(g.numpy(), h.numpy(), None if s is None else s.numpy(), go.cpu().numpy(), N, norm)
+    g1, h1 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    m = cspn_amd.Affinity_Propagate(N, 3, norm)
+    o = m(g1, h1, sd)
+    assert o.grad_fn is not None and len(o.grad_fn.saved_tensors) == 4 and o.grad_fn.saved_tensors[3] is not None
+    o.backward(go)
+    assert _err(g1.grad.cpu().numpy(), rgg) <= GTOL and _err(h1.grad.cpu().numpy(), rgh) <= GTOL
+    m.keep_history = False
+    g2, h2 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    m(g2, h2, sd).backward(go)
+    assert torch.equal(g2.grad, g1.grad) and torch.equal(h2.grad, h1.grad)
+
+
+@pytest.mark.gpu
 def test_hip_backward_full_size_is_linear_in_grad_out():
     import cspn_amd
     B, H, W = 4, 304, 1216

@@ -38,11 +38,27 @@ def main():
         cspn_amd.cspn2d_backward(g, h, s, go, N, "8sum")
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
+    # a training step through the module (forward + backward), with and without the level history kept by the forward
+    train = {}
+    for keep in (True, False):
+        m = cspn_amd.Affinity_Propagate(N, 3, "8sum")
+        m.keep_history = keep
+        gr, hr = g.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        for _ in range(3):
+            m(gr, hr, s).backward(go)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gr.grad = hr.grad = None
+            m(gr, hr, s).backward(go)
+        torch.cuda.synchronize()
+        train["keep_history" if keep else "recompute"] = round((time.perf_counter() - t0) / a.steps * 1e3, 3)
     px = B * H * W
     alg = px * (80 if a.sparse else 76)
     print(json.dumps({"op": "cspn2d_backward_f32", "B": B, "H": H, "W": W, "n_iter": N, "sparse": a.sparse,
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
+                      "train_step_fwd_bwd_ms": train,
                       "note": "forward and adjoint sweeps each as one launch of the fused ring kernel writing its 23 intermediate "
                               "levels (the forward one also the folded coefficients), + the final pass; workspace 56 planes + the row-descriptor table"}))
 
