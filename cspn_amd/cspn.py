@@ -26,7 +26,7 @@ class _CSPN2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, guidance, blur_depth, sparse_depth, n_iter, norm_type, algo, keep_history):
         ctx.n_iter, ctx.norm_type = n_iter, norm_type
-        needs_grad = guidance.requires_grad or blur_depth.requires_grad
+        needs_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         B, _, H, W = guidance.shape
         if (keep_history and needs_grad and algo in ("auto", "fused") and guidance.is_cuda
                 and F.cspn2d_history_bytes(B, H, W, n_iter) > 0):
