@@ -124,3 +124,26 @@ def cspn2d_backward_check_mask(cspn_amd, gd, hd, sd):
     mask = (sd != 0).float()
     _, hb = cspn_amd.cspn2d_backward(gd, hd, sd, mask, 24, "8sum")
     return bool(((hb - 1.0)[mask.bool()] >= -1e-4).all())
+
+
+@pytest.mark.gpu
+def test_forward_and_backward_vs_stock_torch_autograd_at_full_width():
+    """a plain-torch restatement of the reference ops (tools/torch_path.py) with torch autograd on the GPU: forward and both
+    gradients at KITTI width, larger than the numpy restatement is practical for"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.torch_path import cspn2d_torch
+    import cspn_amd
+    B, H, W, N = 2, 96, 1216, 24
+    g, h, s = make_inputs(B, H, W, seed=31, sparse=True, neg=True, depth_scale=80.0)
+    go = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(8)).cuda()
+    g0, h0 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    ref = cspn2d_torch(g0, h0, s.cuda(), N, "8sum")
+    ref.backward(go)
+    g1, h1 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    out = cspn_amd.Affinity_Propagate(N, 3, "8sum")(g1, h1, s.cuda())
+    out.backward(go)
+    assert _err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-4
+    assert _err(g1.grad.cpu().numpy(), g0.grad.cpu().numpy()) <= GTOL
+    assert _err(h1.grad.cpu().numpy(), h0.grad.cpu().numpy()) <= GTOL
