@@ -49,5 +49,34 @@ if __name__ == "__main__":
             cspn2d_torch(g, h, None, N)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 5 * 1e3
-    print(json.dumps({"path": "stock PyTorch ops on the same GPU (tools/torch_path.py)", "B": B, "H": H, "W": W, "n_iter": N,
-                      "ms_per_forward": round(ms, 3), "Mpix_iters_per_s": round(B * H * W * N / ms / 1e3, 1)}))
+    res = {"path": "stock PyTorch ops on the same GPU (tools/torch_path.py)", "B": B, "H": H, "W": W, "n_iter": N,
+           "ms_per_forward": round(ms, 3), "Mpix_iters_per_s": round(B * H * W * N / ms / 1e3, 1)}
+    if B <= 16:  # forward + backward through torch autograd (it keeps ~27 temporaries per iteration)
+        go = torch.randn_like(h)
+        gr, hr = g.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        for _ in range(2):
+            gr.grad = hr.grad = None
+            cspn2d_torch(gr, hr, None, N).backward(go)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gr.grad = hr.grad = None
+            cspn2d_torch(gr, hr, None, N).backward(go)
+        torch.cuda.synchronize()
+        res["ms_per_forward_backward"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        res["peak_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 2)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import cspn_amd
+        m = cspn_amd.Affinity_Propagate(N, 3, "8sum")
+        for _ in range(3):
+            gr.grad = hr.grad = None
+            m(gr, hr, None).backward(go)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gr.grad = hr.grad = None
+            m(gr, hr, None).backward(go)
+        torch.cuda.synchronize()
+        res["cspn_amd_ms_per_forward_backward"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+    print(json.dumps(res))
