@@ -15,14 +15,32 @@ def make_inputs(B, H, W, seed=0, sparse=True, p_sparse=0.05, depth_scale=10.0, n
     return g, h, s
 
 
-def rel_err(a, b):
-    """max|a-b| / max|b| over finite entries; NaN/Inf positions must coincide."""
+def config_inputs(B, H, W, scale, sparse, seed0=1000, first=0):
+    """BASELINE configs 2-4 with per-image seeding: image i (global index) comes from
+    torch.Generator().manual_seed(seed0 + i) on the CPU, so any sharding of the batch sees identical data."""
+    gs, hs, ss = [], [], []
+    for i in range(first, first + B):
+        gen = torch.Generator().manual_seed(seed0 + i)
+        gs.append(torch.randn(8, H, W, generator=gen))
+        hs.append(torch.rand(1, H, W, generator=gen) * scale)
+        if sparse:
+            m = (torch.rand(1, H, W, generator=gen) < 500.0 / (H * W)).float()
+            ss.append(m * (torch.rand(1, H, W, generator=gen) * scale + 0.1))
+    return torch.stack(gs), torch.stack(hs), (torch.stack(ss) if sparse else None)
+
+
+def _finite_pair(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape
     na, nb = ~np.isfinite(a), ~np.isfinite(b)
     assert np.array_equal(na, nb), "non-finite pattern differs (%d vs %d)" % (na.sum(), nb.sum())
-    fin = ~nb
+    return a, b, ~nb
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| over finite entries; NaN/Inf positions must coincide."""
+    a, b, fin = _finite_pair(a, b)
     if not fin.any():
         return 0.0
     denom = max(np.abs(b[fin]).max(), 1e-30)
@@ -30,3 +48,28 @@ def rel_err(a, b):
 
 
 RTOL = 1e-4  # BASELINE.json north_star: "within 1e-4 relative float tolerance"
+ATOL_FRAC = 1e-4  # assert_close(rtol=1e-4, atol=1e-4 * max|ref|)
+
+
+def assert_close(a, b, what="", rtol=RTOL, atol_frac=ATOL_FRAC):
+    """element-wise |a-b| <= atol + rtol*|b| with atol = atol_frac * max|b| (what
+    torch.testing.assert_close(rtol=1e-4, atol=1e-4*max|ref|) checks), non-finite patterns equal, AND the max-norm
+    figure rel_err() <= rtol.  Returns (rel_err, worst element-wise excess ratio)."""
+    a, b, fin = _finite_pair(a, b)
+    if not fin.any():
+        return 0.0, 0.0
+    scale = max(np.abs(b[fin]).max(), 1e-30)
+    d = np.abs(a[fin] - b[fin])
+    bound = atol_frac * scale + rtol * np.abs(b[fin])
+    worst = float((d / bound).max())
+    err = float(d.max() / scale)
+    assert worst <= 1.0, "%s: element-wise tolerance exceeded by %.3gx (max-norm rel err %.3g)" % (what, worst, err)
+    assert err <= rtol, "%s: max-norm relative error %.3g > %g" % (what, err, rtol)
+    return err, worst
+
+
+def assert_close_tight(a, b, what="", rtol=RTOL, atol_frac=1e-6):
+    """the stricter element-wise form ADVICE r01 asked for on golden / KITTI-shape cases: the absolute floor is
+    1e-6 * max|ref| (instead of 1e-4 * max|ref|), so small-magnitude pixels next to 80 m depths are really checked
+    to 1e-4 relative.  Holds because the engine's error is ~3e-7 of max|ref| (float reordering noise)."""
+    return assert_close(a, b, what, rtol=rtol, atol_frac=atol_frac)

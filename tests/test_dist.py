@@ -39,7 +39,30 @@ def _worker(rank, world, port, q):
         y = torch.arange(6.0).view(6, 1, 1, 1)
         (part,) = cd.shard_batch([y], rank, world)
         full = cd.gather_outputs(part * 2.0)
-        q.put((rank, same, nbytes, lo, hi, mine.flatten().tolist(), full.flatten().tolist()))
+        # uneven shards (7 over 2 ranks -> 4 + 3) gather back in order too
+        full7 = cd.gather_outputs(mine + 10.0)
+        # training: after allreduce_grads_ + an optimizer step both ranks hold bit-identical weights, equal to a
+        # single process stepping on the whole batch (what nn.DataParallel gives the reference, train.py:162-166)
+        torch.manual_seed(7)
+        xb, yb = torch.randn(6, 4, 9, 9), torch.randn(6, 8, 7, 7)
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        (xs, ys) = cd.shard_batch([xb, yb], rank, world)
+        import copy
+        whole = copy.deepcopy(net[0])
+        ((whole(xb) - yb) ** 2).mean().backward()          # single process, whole batch
+        opt.zero_grad()
+        ((net[0](xs) - ys) ** 2).mean().backward()        # conv only: BatchNorm statistics are per-rank by design
+        cd.allreduce_grads_(net)
+        grad_ok = bool(torch.allclose(net[0].weight.grad, whole.weight.grad, rtol=1e-5, atol=1e-7)
+                       and torch.allclose(net[0].bias.grad, whole.bias.grad, rtol=1e-5, atol=1e-7))
+        opt.step()
+        w_after = net[0].weight.detach().clone()
+        gathered = [torch.empty_like(w_after) for _ in range(world)]
+        dist.all_gather(gathered, w_after)
+        identical = bool(torch.equal(gathered[0], gathered[1]))
+        q.put((rank, same, nbytes, lo, hi, mine.flatten().tolist(), full.flatten().tolist(), full7.flatten().tolist(),
+               identical and grad_ok, w_after.numpy(), net[0].weight.grad.detach().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -51,15 +74,20 @@ def test_two_rank_shard_broadcast_gather():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, same0, nb0, lo0, hi0, mine0, full0), (r1, same1, nb1, lo1, hi1, mine1, full1) = res
+    res = sorted(res, key=lambda r: r[0])
+    (r0, same0, nb0, lo0, hi0, mine0, full0, f70, id0, w0, g0), (r1, same1, nb1, lo1, hi1, mine1, full1, f71, id1, w1, g1) = res
     assert same0 and same1 and nb0 == nb1 > 0
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)
     assert mine0 == [0, 1, 2, 3] and mine1 == [4, 5, 6]
     assert full0 == full1 == [0, 2, 4, 6, 8, 10]
+    assert f70 == f71 == [10, 11, 12, 13, 14, 15, 16]
+    assert id0 and id1
+    import numpy as np
+    assert np.array_equal(w0, w1) and np.array_equal(g0, g1)
 
 
 def test_shard_range_covers_everything():

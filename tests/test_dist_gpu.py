@@ -1,0 +1,91 @@
+"""Two ranks on the one GPU of the test box (gloo for the control plane, both ranks on cuda:0): the engine under
+torch.distributed exactly as bench.py --gpus N drives it -- per-image-seeded batch, shard_batch, one
+forward per rank, gather -- equals the single-rank result bit for bit; and bench.py's own rank plumbing runs under
+torch.distributed.run.  RCCL needs one device per rank, so on an 8-GPU node the same code runs with backend "nccl"."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, H, W, sparse, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, ROOT)
+        import cspn_amd
+        from cspn_amd import dist as cd
+        from helpers import config_inputs
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        g, h, s = config_inputs(B, H, W, 80.0, sparse)             # the whole global batch, identical on every rank
+        gs, hs, ss = cd.shard_batch([g, h, s], rank, world)
+        out = cspn_amd.cspn2d_forward(gs.cuda(), hs.cuda(), None if ss is None else ss.cuda(), 24, "8sum")
+        torch.cuda.synchronize()
+        full = cd.gather_outputs(out.cpu())                        # gloo: host tensors
+        same = None
+        if rank == 0:
+            single = cspn_amd.cspn2d_forward(g.cuda(), h.cuda(), None if s is None else s.cuda(), 24, "8sum")
+            torch.cuda.synchronize()
+            same = bool(torch.equal(single.cpu(), full))
+        q.put((rank, tuple(full.shape), same, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:  # surface the traceback in the parent instead of a bare exit code
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("B,H,W,sparse", [(5, 304, 1216, False), (6, 64, 256, True)])
+def test_two_ranks_share_one_gpu_bit_identical(B, H, W, sparse):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, H, W, sparse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+    for rank, shape, same, err in res:
+        assert err is None, err
+        assert shape == (B, 1, H, W)
+        if rank == 0:
+            assert same is True
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_two_ranks_launch_path():
+    """bench.py under torch.distributed.run with 2 ranks on this box's GPU (shared_gpu mode: gloo, no broadcast):
+    the exact command line the driver uses for N > 1, at a small batch."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--batch-per-gpu", "4", "--prewarm-s", "0.1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
+    assert res["parity_checked"]["ok"] and res["parity_checked"]["all_ranks_ok"]
+    assert res["value"] > 0 and res["roofline"]["frac"] > 0
