@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__
     aout[idx] = acc;
 }
 
-__device__ __forceinline__ size_t swz(size_t i) {  // register order (c0,c2,c1,c3) inside each aligned group of 4 columns
-    const size_t e = i & 3;
-    return (i & ~(size_t)3) | (e == 1 ? 2 : (e == 2 ? 1 : e));
+__device__ __forceinline__ size_t swz(size_t i) {  // register order (c0,c3,c1,c2) inside each aligned group of 4 columns
+    const size_t e = i & 3;                           // (tools/tswgen/kernel.py: the pairs X = (c0,c3), Y = (c1,c2))
+    return (i & ~(size_t)3) | (e == 1 ? 2 : (e == 2 ? 3 : (e == 3 ? 1 : 0)));
 }
 
 // hh: H_1 .. H_{N-1} (H_0 = blur).  SWZ = false: ah = A_0 .. A_{N-1}, plain layout (stepwise sweeps).
@@ -167,8 +167,8 @@ static bool asm_path(int B, int H, int W, int n_iter) {
 
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
-    if (asm_path(B, H, W, n_iter))  // forward levels 23 + folded coefficients 8 + adjoint levels 23 + A_0 + a scratch output, plan
-        return FRONT_PAD + (size_t)(23 + 8 + 23 + 2) * total * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
+    if (asm_path(B, H, W, n_iter))  // forward levels 23 + folded coefficients 8 + adjoint levels 23 + A_0 + a scratch output
+        return FRONT_PAD + (size_t)(23 + 8 + 23 + 2) * total * sizeof(float) + 256;
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
@@ -186,11 +186,9 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         float* ah = wf + 8 * total;
         float* a0 = ah + 23 * total;
         float* scratch = a0 + total;
-        void* plan = (void*)(((uintptr_t)(scratch + total) + 255) & ~(uintptr_t)255);
         const unsigned blocks = (unsigned)((total + 255) / 256);
-        if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
-        if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, plan, st, hh)) return e;
-        if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, plan, st, ah)) return e;
+        if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, st, hh)) return e;
+        if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
         hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
                            H, W, n_iter, norm);
         return check_launch("bwd_final_kernel");
@@ -223,12 +221,12 @@ size_t history2d_bytes(int B, int H, int W, int n_iter) {
 int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
                       int norm, void* ws, hipStream_t st) {
     float* hh = (float*)((char*)history + FRONT_PAD);
-    if (int e = tsw2d_build_plan(B, H, W, ws, st)) return e;
-    return tsw2d_pass(g, blur, blur, sparse, out, B, H, W, norm, ws, st, hh);
+    (void)ws;
+    return tsw2d_pass(g, blur, blur, sparse, out, B, H, W, norm, st, hh);
 }
 
 size_t backward2d_history_workspace(int B, int H, int W) {
-    return (size_t)(23 + 1) * B * H * W * sizeof(float) + 256 + tsw2d_plan_bytes(B, H, W);
+    return (size_t)(23 + 1) * B * H * W * sizeof(float) + 256;
 }
 
 int backward2d_history(const float* g, const float* blur, const float* sparse, const float* gout, const void* history, float* gg,
@@ -238,9 +236,7 @@ int backward2d_history(const float* g, const float* blur, const float* sparse, c
     const float* wf = hh + 23 * total;
     float* ah = (float*)ws;
     float* a0 = ah + 23 * total;
-    void* plan = (void*)(((uintptr_t)(a0 + total) + 255) & ~(uintptr_t)255);
-    if (int e = tsw2d_build_plan(B, H, W, plan, st)) return e;
-    if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, plan, st, ah)) return e;
+    if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
     hipLaunchKernelGGL(bwd_final_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
                        gout, gg, gb, B, H, W, 24, norm);
     return check_launch("bwd_final_kernel");

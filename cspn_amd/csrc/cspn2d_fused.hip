@@ -568,9 +568,7 @@ static size_t ping_bytes(int B, int H, int W, int n_iter) {
 }
 
 size_t fused2d_workspace(int B, int H, int W, int n_iter) {
-    // + the row-descriptor table of the assembly passes (cspn2d_tsw.hip), used by every pass of exactly 24 iterations
-    const size_t plan = (n_iter >= LV && tsw2d_supported(B, H, W)) ? tsw2d_plan_bytes(B, H, W) : 0;
-    return ping_bytes(B, H, W, n_iter) + plan;
+    return ping_bytes(B, H, W, n_iter);   // the assembly passes plan their streams in the kernel: no table in HBM
 }
 
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
@@ -578,11 +576,7 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
     if (((uintptr_t)out & 15u) != 0) { set_error("fused kernel needs a 16-byte aligned output"); return CSPN_E_UNSUPPORTED; }
     const int passes = (n_iter + LV - 1) / LV;
     float* pingpong = (float*)ws;
-    void* plan_ws = (char*)ws + ping_bytes(B, H, W, n_iter);
     const bool asm_ok = use_asm && n_iter >= LV && tsw2d_supported(B, H, W);
-    if (asm_ok) {
-        if (int e = tsw2d_build_plan(B, H, W, plan_ws, st)) return e;
-    }
     const float* hin = blur;
     int done = 0;
     for (int p = 0; p < passes; ++p) {
@@ -590,7 +584,7 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
         if (asm_ok && n == LV) {
-            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, plan_ws, st)) return e;
+            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
             hin = dst;
             done += n;
             continue;

@@ -40,12 +40,9 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
 
 // ---- the same ring with the main loop in gfx950 assembly (cspn2d_tsw.hip); one pass = exactly 24 iterations ----
 bool tsw2d_supported(int B, int H, int W);
-size_t tsw2d_plan_bytes(int B, int H, int W);
-int tsw2d_build_plan(int B, int H, int W, void* plan_ws, hipStream_t st);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
-               int W, int norm, const void* plan_ws, hipStream_t st, float* hist = nullptr);
-int tsw2d_adjoint_pass(const float* wf, const float* a_in, float* a0, int B, int H, int W, const void* plan_ws, hipStream_t st,
-                       float* hist);
+               int W, int norm, hipStream_t st, float* hist = nullptr);
+int tsw2d_adjoint_pass(const float* wf, const float* a_in, float* a0, int B, int H, int W, hipStream_t st, float* hist);
 
 // ---- backward of the 2D op (cspn2d_backward.hip) ----
 size_t backward2d_workspace(int B, int H, int W, int n_iter);

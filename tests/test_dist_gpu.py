@@ -1,7 +1,13 @@
 """Two ranks on the one GPU of the test box (gloo for the control plane, both ranks on cuda:0): the engine under
 torch.distributed exactly as bench.py --gpus N drives it -- per-image-seeded batch, shard_batch, one
-forward per rank, gather -- equals the single-rank result bit for bit; and bench.py's own rank plumbing runs under
-torch.distributed.run.  RCCL needs one device per rank, so on an 8-GPU node the same code runs with backend "nccl"."""
+forward per rank, gather -- equals the single-rank result; and bench.py's own rank plumbing runs under
+torch.distributed.run.  RCCL needs one device per rank, so on an 8-GPU node the same code runs with backend "nccl".
+
+"Equals": to float-reordering noise (<= 2e-6 of the largest depth, observed ~3e-7), not bit for bit -- in the fused ring
+the order in which a row's nine terms are summed depends on the ring slot the row lands in (slot 0 adds its own taps
+before the taps of the row above, slots 1-3 after), and the slot is a function of the row's position in the workgroup's
+stream, i.e. of the batch size.  For a FIXED shape the result is bit-reproducible (test_asm_paths_are_deterministic), and
+the one-launch-per-iteration path, whose summation order is position independent, is compared bit for bit here."""
 import json
 import os
 import socket
@@ -38,14 +44,21 @@ def _worker(rank, world, port, B, H, W, sparse, q):
         torch.cuda.set_device(0)
         g, h, s = config_inputs(B, H, W, 80.0, sparse)             # the whole global batch, identical on every rank
         gs, hs, ss = cd.shard_batch([g, h, s], rank, world)
-        out = cspn_amd.cspn2d_forward(gs.cuda(), hs.cuda(), None if ss is None else ss.cuda(), 24, "8sum")
+        args = (gs.cuda(), hs.cuda(), None if ss is None else ss.cuda(), 24, "8sum")
+        out = cspn_amd.cspn2d_forward(*args)
+        out_sw = cspn_amd.cspn2d_forward(*args, algo="stepwise")
         torch.cuda.synchronize()
         full = cd.gather_outputs(out.cpu())                        # gloo: host tensors
+        full_sw = cd.gather_outputs(out_sw.cpu())
         same = None
         if rank == 0:
-            single = cspn_amd.cspn2d_forward(g.cuda(), h.cuda(), None if s is None else s.cuda(), 24, "8sum")
+            args = (g.cuda(), h.cuda(), None if s is None else s.cuda(), 24, "8sum")
+            single = cspn_amd.cspn2d_forward(*args).cpu()
+            single_sw = cspn_amd.cspn2d_forward(*args, algo="stepwise").cpu()
             torch.cuda.synchronize()
-            same = bool(torch.equal(single.cpu(), full))
+            scale = float(single.abs().max())
+            same = (bool(torch.equal(single_sw, full_sw)),                              # position-independent path: bit for bit
+                    float((single - full).abs().max()) / scale)                         # fused ring: reordering noise only
         q.put((rank, tuple(full.shape), same, None))
         dist.barrier()
         dist.destroy_process_group()
@@ -70,7 +83,8 @@ def test_two_ranks_share_one_gpu_bit_identical(B, H, W, sparse):
         assert err is None, err
         assert shape == (B, 1, H, W)
         if rank == 0:
-            assert same is True
+            assert same[0] is True
+            assert same[1] <= 2e-6, same
     assert all(p.exitcode == 0 for p in procs)
 
 

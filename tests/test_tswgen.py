@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools.tswgen import kernel as K  # noqa: E402
 from tools.tswgen.isa import check_hazards  # noqa: E402
-from tools.tswgen.run_emu import run_case  # noqa: E402
+from tools.tswgen.run_emu import fill_table, run_case  # noqa: E402
 
 CASES = [
     # B, H, W, n_wg, norm, sparse, hin, zero_patch
@@ -74,6 +74,7 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
         if hdr[wg, 0] == 0:
             continue
         emu = Emu(prog, mem, K.LDS_BYTES)
+        fill_table(emu, tab[wg])
         for w in emu.waves:
             w.v[0] = np.arange(64, dtype=np.uint32)
             for r, v in ((K.S_GD, off["gd"]), (K.S_BLUR, off["blur"]), (K.S_HIN, 4096), (K.S_SP, 4096), (K.S_OUT, off["out"]),
@@ -83,7 +84,7 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
             w.s[K.S_NROWS.i], w.s[K.S_LOHI.i] = tab.shape[1], int(hdr[wg, 2])
         emu.run()
     out = mem[off["out"]:off["out"] + total * 4].view(np.float32).reshape(B, H, W)
-    hb = mem[off["hist"]:off["hist"] + 23 * total * 4].view(np.float32).reshape(23, B, H, W // 4, 4)[..., [0, 2, 1, 3]].reshape(23, B, H, W)
+    hb = mem[off["hist"]:off["hist"] + 23 * total * 4].view(np.float32).reshape(23, B, H, W // 4, 4)[..., [0, 2, 3, 1]].reshape(23, B, H, W)
     assert np.abs(out - levels[23]).max() <= 1e-5 * np.abs(levels[23]).max()
     for n in range(1, 24):
         assert np.abs(hb[n - 1] - levels[n - 1]).max() <= 1e-5 * np.abs(levels[n - 1]).max(), n

@@ -228,6 +228,12 @@ class Emu(object):
         elif o == "s_cbranch_scc1":
             if w.scc:
                 nxt = self.labels[s[0]]
+        elif o == "s_cbranch_vccnz":
+            if int(w.vcc) != 0:
+                nxt = self.labels[s[0]]
+        elif o == "s_cbranch_vccz":
+            if int(w.vcc) == 0:
+                nxt = self.labels[s[0]]
         elif o == "s_cbranch_execz":
             if int(w.exec) == 0:
                 nxt = self.labels[s[0]]
@@ -364,6 +370,12 @@ class Emu(object):
                     else:
                         raise EmuError("dpp ctrl " + m["dpp"])
                 self.wv(w, d[0], x)
+            elif o == "v_pk_mov_b32":
+                # D.lo = S0[op_sel[0]], D.hi = S1[op_sel[1]] (LLVM SIInstrInfo::copyPhysReg uses op_sel:[0,1] for a 64-bit copy)
+                osl = m.get("op_sel", [0, 0])
+                lo, hi = rv(w, s[0], osl[0]).copy(), rv(w, s[1], osl[1]).copy()
+                self.wv(w, d[0], lo, 0)
+                self.wv(w, d[0], hi, 1)
             elif o in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
                 nsrc = len(s)
                 osl = m.get("op_sel", [0] * nsrc)
@@ -449,11 +461,22 @@ class Emu(object):
             for k in range(ndw):
                 self.lds[idx[ex, k]] = self.rv(w, s[1], k)[ex]
             w.lds_q.append([])
-        elif o == "ds_write2_b32":
+        elif o in ("ds_write2_b32", "ds_write2st64_b32"):
+            unit = 4 if o == "ds_write2_b32" else 256
             for src, off in ((s[1], m.get("offset0", 0)), (s[2], m.get("offset1", 0))):
-                idx = self.lds_access(w, addr + 4 * off, 1, True, ex, 4)
+                idx = self.lds_access(w, addr + unit * off, 1, True, ex, 4)
                 self.lds[idx[ex, 0]] = self.rv(w, src)[ex]
             w.lds_q.append([])
+        elif o in ("ds_read2_b32", "ds_read2st64_b32"):
+            unit = 4 if o == "ds_read2_b32" else 256
+            regs = [("v", d[0].i), ("v", d[0].i + 1)]
+            vals = []
+            for off in (m.get("offset0", 0), m.get("offset1", 0)):
+                idx = self.lds_access(w, addr + unit * off, 1, False, ex, 4)
+                vals.append(self.lds[idx[:, 0]])
+            for k in range(2):
+                self.wv(w, d[0], vals[k], k)
+            self._pend(w, regs, w.lds_q)
         else:
             raise EmuError("unknown DS op " + o)
 

@@ -75,17 +75,18 @@ def optext(o):
 
 
 # opcode classes
-VOP_PK = {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"}
+VOP_PK = {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32"}
 VOP_TRANS = {"v_rcp_f32"}
 VOP_E32 = {"v_mov_b32", "v_rcp_f32", "v_lshlrev_b32", "v_lshrrev_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32",
            "v_mul_f32", "v_add_f32", "v_sub_f32", "v_mul_u32_u24", "v_xor_b32"}
 VOP_E64 = {"v_fma_f32", "v_cndmask_b32", "v_cmp_ge_u32", "v_cmp_lt_u32", "v_cmp_gt_f32", "v_cmp_lt_f32", "v_cmp_eq_u32",
            "v_mad_u32_u24"}
-DS_OPS = {"ds_read_b128", "ds_write_b128", "ds_write2_b32", "ds_read_b64", "ds_write_b64", "ds_write_b32", "ds_read_b32"}
+DS_OPS = {"ds_read_b128", "ds_write_b128", "ds_write2_b32", "ds_read_b64", "ds_write_b64", "ds_write_b32", "ds_read_b32",
+          "ds_read2st64_b32", "ds_write2st64_b32", "ds_read2_b32"}
 VMEM_LD = {"global_load_dwordx2", "global_load_dword", "global_load_dwordx4"}
 VMEM_ST = {"global_store_dwordx4", "global_store_dwordx2", "global_store_dword"}
 SMEM = {"s_load_dwordx8", "s_load_dwordx4", "s_load_dwordx2", "s_load_dword"}
-BRANCH = {"s_cbranch_scc0", "s_cbranch_scc1", "s_branch", "s_cbranch_execz"}
+BRANCH = {"s_cbranch_scc0", "s_cbranch_scc1", "s_branch", "s_cbranch_execz", "s_cbranch_vccnz", "s_cbranch_vccz"}
 SCC_WRITERS = {"s_add_u32", "s_addc_u32", "s_subb_u32", "s_add_i32", "s_sub_i32", "s_sub_u32", "s_lshl_b32", "s_lshr_b32", "s_and_b32",
                "s_or_b32", "s_xor_b32", "s_andn2_b32", "s_and_b64", "s_or_b64", "s_andn2_b64", "s_and_saveexec_b64",
                "s_bitcmp1_b32", "s_bitcmp0_b32", "s_ashr_i32", "s_bfe_u32"}
@@ -170,9 +171,13 @@ class I(object):
         if o in BRANCH:
             return "%s %s" % (o, s[0])
         if o in DS_OPS:
+            if o in ("ds_read2st64_b32", "ds_read2_b32"):
+                assert 0 <= m.get("offset0", 0) < 256 and 0 <= m.get("offset1", 0) < 256, m
+                return "%s %s, %s offset0:%d offset1:%d" % (o, optext(d[0]), optext(s[0]), m.get("offset0", 0), m.get("offset1", 0))
             if o.startswith("ds_read"):
                 t = "%s %s, %s" % (o, optext(d[0]), optext(s[0]))
-            elif o == "ds_write2_b32":
+            elif o in ("ds_write2_b32", "ds_write2st64_b32"):
+                assert 0 <= m.get("offset0", 0) < 256 and 0 <= m.get("offset1", 0) < 256, m
                 return "%s %s, %s, %s offset0:%d offset1:%d" % (o, optext(s[0]), optext(s[1]), optext(s[2]),
                                                                  m.get("offset0", 0), m.get("offset1", 0))
             else:

@@ -12,7 +12,7 @@ Register / LDS maps are module constants; `build(cfg)` returns an isa.Prog.
 cfg: norm (0 '8sum', 1 '8sum_abs', 2 'none'), sparse (bool), hin (bool: level-0 values come from a previous pass),
 n_iter (only 24 for now).
 """
-from .isa import Prog, V, S, EXEC, schedule, check_hazards, expand_pseudos
+from .isa import Prog, V, S, EXEC, VCC, schedule, check_hazards, expand_pseudos
 
 NW, NSLOT, LV = 8, 4, 24
 PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
@@ -38,6 +38,10 @@ V_TMP = V(21)
 V_DE, V_DO, V_DC = V(21), V(22, 2), V(252, 4)  # descriptor fetches (event: new row's d3, old row's d2:d3; cooking: whole row)
 V_DN = V(74, 2)                                 # history mode: new row's d2:d3
 TQ, BQ, TA, TB, HN, HA, OUTQ = V(24, 4), V(28, 4), V(32, 4), V(36, 4), V(40, 4), V(44, 4), V(48, 4)
+# one pair per shifted row value of a step (D = (c3 of lane-1, c0 of lane+1)), so that the pushes nobody waits for can
+# trail behind the chain: received rows, slots 3..1, and slot 0's deferred pushes (cooking, at the top of a step, uses
+# TA, TB and OUTQ[0:1] while only D_TAIL is live)
+D_BQ, D_TQ, D_SLOT, D_TAIL = OUTQ.sub(0, 2), TB.sub(2, 2), {3: TA.sub(0, 2), 2: TA.sub(2, 2), 1: TB.sub(0, 2)}, OUTQ.sub(2, 2)
 CK = V(24, 28)  # cooking temporaries alias the step temporaries
 PEND_G = [V(52 + 2 * k, 2) for k in range(8)]
 PEND_BLUR, PEND_HIN, PEND_SP = V(68, 2), V(70, 2), V(72, 2)
@@ -103,45 +107,66 @@ class Gen(object):
         keep = m.pop("keep", False)
         if "nostep" in self.ab and not keep:
             return
+        if m.pop("late", False) and self.cfg.get("late_at") is not None:
+            m["at"] = self.cfg["late_at"]   # nobody in this step waits for the result: keep it out of the way of the chain
         self.e("v_pk_fma_f32", d, [a, b, c], **m)
 
     def mov(self, d, s):
         self.e("v_mov_b32", d, s)
 
+    # Register layout of a row (4 columns c0..c3 per lane): the quad (c0, c3, c1, c2), i.e. the pairs X = (c0,c3) and
+    # Y = (c1,c2).  With D = (c3 of lane-1, c0 of lane+1) -- two DPP moves -- every tap of every column is one half of a
+    # v_pk_fma_f32 whose two h operands sit in ONE aligned register pair, so no value is ever copied:
+    #   dst X = (a0,a3):  x   : X = (h0,h3)          x+1|x-1 : Y = (h1,h2)           x-1|x+1 : D = (h-1,h4)
+    #   dst Y = (a1,a2):  x   : Y = (h1,h2)          x+1|x-1 : Y swapped (op_sel)    x-1|x+1 : X = (h0,h3)
+    # The coefficient registers are laid out to match (WT(j, q), q = 0..8): for a row of taps with planes (kr, km, kl) =
+    # (dx = +1, 0, -1) the quads  R = (kr0, kl3, kr1, kl2),  M = (km0, km3, km1, km2),  L = (kl0, kr3, kl1, kr2);
+    # q = 0,1,2: below taps (planes 0,1,2)   q = 3,4: self taps R, L (planes 3,4)   q = 5,6,7: above taps (planes 5,6,7)
+    # q = 8: c'.  inject() builds them straight out of the LDS ring with ds_read2st64_b32 (ring layout [plane][column][lane]).
     def shift(self, q, t):
-        """q = (c0,c2,c1,c3); t <- xl=(c3 of lane-1, c1), xr=(c2, c0 of lane+1)"""
+        """q = (c0,c3,c1,c2); t[0:1] <- D = (c3 of lane-1, c0 of lane+1)"""
         if "nostep" in self.ab:
             return
-        self.e("v_mov_b32", t[0], q[3], dpp="wave_shr:1")
-        self.e("v_mov_b32", t[3], q[0], dpp="wave_shl:1")
-        self.mov(t[1], q[2])
-        self.mov(t[2], q[1])
+        self.e("v_mov_b32", t[0], q[1], dpp="wave_shr:1")
+        self.e("v_mov_b32", t[1], q[0], dpp="wave_shl:1")
 
-    def push3(self, kr, km, kl, j, q, t, acc, init=None):
-        p0, p1, xl, xr = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2), t.sub(2, 2)
-        a0, a1 = acc.sub(0, 2), acc.sub(2, 2)
-        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (a0, a1)
-        self.fma(a0, WT(j, kr).sub(0, 2), p1, c0)
-        self.fma(a1, WT(j, kr).sub(2, 2), xr, c1)
-        self.fma(a0, WT(j, km).sub(0, 2), p0, a0)
-        self.fma(a1, WT(j, km).sub(2, 2), p1, a1)
-        self.fma(a0, WT(j, kl).sub(0, 2), xl, a0)
-        self.fma(a1, WT(j, kl).sub(2, 2), p0, a1)
+    SWAP = dict(op_sel=[0, 1, 0], op_sel_hi=[1, 0, 1])   # src1 halves exchanged
+
+    def push3(self, qr, qm, ql, j, q, t, acc, init=None, late=False):
+        X, Y, D = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2)
+        ax, ay = acc.sub(0, 2), acc.sub(2, 2)
+        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (ax, ay)
+        self.fma(ax, WT(j, qm).sub(0, 2), X, c0, late=late)
+        self.fma(ay, WT(j, qm).sub(2, 2), Y, c1, late=late)
+        self.fma(ax, WT(j, qr).sub(0, 2), Y, ax, late=late)
+        self.fma(ay, WT(j, qr).sub(2, 2), Y, ay, late=late, **self.SWAP)
+        self.fma(ay, WT(j, ql).sub(2, 2), X, ay, late=late)
+        self.fma(ax, WT(j, ql).sub(0, 2), D, ax, late=late)
 
     def push_below(self, j, q, t, acc, init=None):
         self.push3(0, 1, 2, j, q, t, acc, init)
 
-    def push_above(self, j, q, t, acc, init=None):
-        self.push3(5, 6, 7, j, q, t, acc, init)
+    def push_above(self, j, q, t, acc, init=None, late=False):
+        self.push3(5, 6, 7, j, q, t, acc, init, late=late)
 
-    def push_self(self, j, q, t, acc, init=None):
-        p0, p1, xl, xr = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2), t.sub(2, 2)
-        a0, a1 = acc.sub(0, 2), acc.sub(2, 2)
-        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (a0, a1)
-        self.fma(a0, WT(j, 3).sub(0, 2), p1, c0)
-        self.fma(a1, WT(j, 3).sub(2, 2), xr, c1)
-        self.fma(a0, WT(j, 4).sub(0, 2), xl, a0)
-        self.fma(a1, WT(j, 4).sub(2, 2), p0, a1)
+    def push_self(self, j, q, t, acc, init=None, late=False):
+        X, Y, D = q.sub(0, 2), q.sub(2, 2), t.sub(0, 2)
+        ax, ay = acc.sub(0, 2), acc.sub(2, 2)
+        c0, c1 = (init.sub(0, 2), init.sub(2, 2)) if init is not None else (ax, ay)
+        self.fma(ax, WT(j, 3).sub(0, 2), Y, c0, late=late)
+        self.fma(ay, WT(j, 3).sub(2, 2), Y, c1, late=late, **self.SWAP)
+        self.fma(ay, WT(j, 4).sub(2, 2), X, ay, late=late)
+        self.fma(ax, WT(j, 4).sub(0, 2), D, ax, late=late)
+
+    # ring: [slot][plane 0..9][column 0..3][lane 0..63] floats; plane 8 = c', plane 9 = H0
+    QUADS = {0: (0, 2), 2: (2, 0), 3: (3, 4), 4: (4, 3), 5: (5, 7), 7: (7, 5)}   # q -> (plane of elements 0,2 ; of elements 1,3)
+
+    def ring_read(self, dst, slot, q, **m):
+        """dst quad <- coefficient quad q (or plane 8 / 9 in (c0,c3,c1,c2) order) of ring slot `slot` (0..3 of this wave's half)"""
+        pa, pb = self.QUADS.get(q, (q, q))
+        base = slot * (RING_SLOT // 256)
+        self.e("ds_read2st64_b32", dst.sub(0, 2), [V_RINGR], offset0=base + pa * 4 + 0, offset1=base + pb * 4 + 3, **m)
+        self.e("ds_read2st64_b32", dst.sub(2, 2), [V_RINGR], offset0=base + pa * 4 + 1, offset1=base + pb * 4 + 2, **m)
 
     def zero_quad(self, q):
         for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
@@ -192,10 +217,10 @@ class Gen(object):
         self.e("s_cbranch_scc0", (), [lab])
         self.e("s_bitcmp1_b32", (), [eo[1], F_OWNED])
         self.e("s_cbranch_scc0", (), [lab])
-        self.mov(OUTQ[0], vq[0])
+        self.mov(OUTQ[0], vq[0])   # registers hold (c0,c3,c1,c2)
         self.mov(OUTQ[1], vq[2])
-        self.mov(OUTQ[2], vq[1])
-        self.mov(OUTQ[3], vq[3])
+        self.mov(OUTQ[2], vq[3])
+        self.mov(OUTQ[3], vq[1])
         self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
         self.e("s_addc_u32", T[9], [S_OUT[1], 0])
         self.e("s_mov_b64", EXEC, [S_OMASK])   # the owned columns are the same for every row of this workgroup's band
@@ -206,16 +231,15 @@ class Gen(object):
 
     def inject(self, j, vq):
         for k in self.late_planes(j):
-            self.e("ds_read_b128", WT(j, k), [V_RINGR], offset=j * RING_SLOT + k * 1024, at=0.0)
-        # the ring holds image order (c0,c1,c2,c3); registers hold (c0,c2,c1,c3)
-        self.mov(vq[0], HN[0])
-        self.mov(vq[3], HN[3])
-        self.mov(vq[2], HN[1])
-        self.mov(vq[1], HN[2])
+            self.ring_read(WT(j, k), j, k, at=0.0)
+        for i in (1, 0, 2, 3):   # the DPP sources first
+            self.mov(vq[i], HN[i])
         self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
         self.e("s_bitcmp1_b32", (), [S_ENF, F_ACTIVE])
         self.e("s_cselect_b32", T[2], [1 << j, 0])
         self.e("s_or_b32", S_ACT, [S_ACT, T[2]])
+        self.e("s_cmp_lg_u32", (), [S_ACT, 15])           # vcc != 0 <=> some slot holds a separator / padding row:
+        self.e("s_cselect_b64", VCC, [1, 0])              # the per-slot checks of the event-free steps are one branch each
         if j == 3:
             self.e("s_add_i32", S_QB, [S_QB, 32])
         if self.hist:  # where the row's levels go and which lanes own its columns
@@ -225,7 +249,7 @@ class Gen(object):
             self.e("s_addc_u32", S_HB[j][1], [S_HIST[1], 0])
 
     def hist_store(self, j, vq):
-        """history mode: the level slot j just completed (1..23), in register order (c0,c2,c1,c3) per 4-column group"""
+        """history mode: the level slot j just completed (1..23), in register order (c0,c3,c1,c2) per 4-column group"""
         self.e("s_mov_b64", EXEC, [S_HM[j]])
         self.e("global_store_dwordx4", (), [V_L16, vq, S_HB[j]])
         self.e("s_mov_b64", EXEC, [-1])
@@ -243,19 +267,15 @@ class Gen(object):
     def late_planes(j):
         return (0, 1, 2, 5, 6, 7) if j == 0 else (0, 1, 2)
 
-    def swap_planes(self, j, planes):
-        for k in planes:  # the ring holds image order (c0,c1,c2,c3); registers hold (c0,c2,c1,c3)
-            self.e("v_swap_b32", [WT(j, k)[1], WT(j, k)[2]], [WT(j, k)[2], WT(j, k)[1]])
-
     def act_check(self, j, vq):
         """a slot holding a separator / padding row is pinned to zero (0 x NaN from a neighbour must not leak into it).
         Modelled as one pseudo instruction so that the scheduler may move independent work across it; the zeroing stub
         lives out of line."""
         stub, back = self.p.newlabel("actz"), self.p.newlabel("actb")
         from .isa import I
-        exp = [I("s_bitcmp1_b32", (), [S_ACT, j]), I("s_cbranch_scc0", (), [stub]), I("label", (), [back])]
-        self.e("pseudo", (), (), expand=exp, reads=[("s", S_ACT.i)] + vq.regs(), writes=[("scc", 0)] + vq.regs())
-        self.stubs.append((stub, back, vq))
+        exp = [I("s_cbranch_vccnz", (), [stub]), I("label", (), [back])]
+        self.e("pseudo", (), (), expand=exp, reads=[("s", S_ACT.i), ("vcc", 0), ("vcc", 1)] + vq.regs(), writes=[("scc", 0)] + vq.regs())
+        self.stubs.append((stub, back, vq, j))
 
     def tail(self, c, skip_above1=False):
         """the part of step c nobody else waits for (slot 0's pushes after its value was published); emitted at the top of
@@ -263,10 +283,10 @@ class Gen(object):
         following step, the accumulator this push would start is re-initialised there"""
         p = c & 1
         v0 = ACC(p, 0)
-        self.shift(v0, TB)
-        self.push_self(0, v0, TB, ACC(p ^ 1, 0), init=WT(0, 8))
+        self.shift(v0, D_TAIL)
+        self.push_self(0, v0, D_TAIL, ACC(p ^ 1, 0), init=WT(0, 8))
         if not skip_above1:
-            self.push_above(1, v0, TB, ACC(p, 1), init=WT(1, 8))
+            self.push_above(1, v0, D_TAIL, ACC(p, 1), init=WT(1, 8))
 
     def step(self, c):
         p = c & 1
@@ -299,12 +319,12 @@ class Gen(object):
             self.e("ds_read_b128", TQ, [V_RT[p]], at=0.0)
         if ev is not None:
             self.fetch_event(ev)
-            self.e("ds_read_b128", HN, [V_RINGR], offset=ev * RING_SLOT + 9 * 1024, at=0.0)
+            self.ring_read(HN, ev, 9, at=0.0)
             if ev > 0:
-                self.e("ds_read_b128", HA, [V_RINGR], offset=(ev - 1) * RING_SLOT + 9 * 1024, at=0.0)
+                self.ring_read(HA, ev - 1, 9, at=0.0)
             if ev > 0:
                 for k in self.early_planes(ev):
-                    self.e("ds_read_b128", WT(ev, k), [V_RINGR], offset=ev * RING_SLOT + k * 1024, at=0.0)
+                    self.ring_read(WT(ev, k), ev, k, at=0.0)
         if cook:
             self.fetch_cook()
         loads = []
@@ -317,13 +337,14 @@ class Gen(object):
         self.tail((c - 1) % LV, skip_above1=(ev == 1))
         if ev == 0:  # slot 0's self taps were still needed by the deferred tail
             for k in self.early_planes(0):
-                self.e("ds_read_b128", WT(0, k), [V_RINGR], offset=k * 1024, at=0.0)
-        self.p.waitcnt(lgkm=0)
-        if pev is not None:
-            self.swap_planes(pev, self.late_planes(pev))
+                self.ring_read(WT(0, k), 0, k, at=0.0)
+        # LDS operations of a wave complete in order: everything this step reads was requested before the ten ring writes of
+        # the cooking, so there is no need to wait for those
+        partial = (cook and ev != 0 and not stag and self.cfg.get("partial_wait", False)
+                   and not ({"nocookwrite", "nocookmath"} & self.ab))
+        self.p.waitcnt(lgkm=10 if partial else 0)
         if ev is not None:
             self.take_event()
-            self.swap_planes(ev, self.early_planes(ev))
         if cook:
             lab = guard()
             self.take_cook()
@@ -338,14 +359,14 @@ class Gen(object):
             if lab:
                 self.p.label(lab)
         # received boundary rows
-        self.shift(BQ, TA)
-        self.push_below(3, BQ, TA, N1[3])
-        self.shift(TQ, TB)
-        self.push_above(0, TQ, TB, N1[0])
-        shifts = [TB, TA, TB, TA]  # temp quad for slot j's value: slot 3 -> TA ... alternate
+        self.shift(BQ, D_BQ)
+        self.push_below(3, BQ, D_BQ, N1[3])
+        self.shift(TQ, D_TQ)
+        self.push_above(0, TQ, D_TQ, N1[0])
+        late = self.cfg.get("late_at") is not None
         for j in (3, 2, 1, 0):
             vq = N1[j]
-            tq = shifts[j]
+            tq = D_SLOT.get(j)
             if ev == j:
                 self.retire(j, vq)
                 self.inject(j, vq)
@@ -362,19 +383,17 @@ class Gen(object):
             self.shift(vq, tq)
             self.push_below(j - 1, vq, tq, N1[j - 1])
             if ev == j:
-                self.push_self(j, vq, tq, N2[j], init=WT(j, 8))
-                self.e("v_swap_b32", [HA[1], HA[2]], [HA[2], HA[1]])
-                self.shift(HA, OUTQ)
-                self.push_above(j, HA, OUTQ, N2[j])
+                self.push_self(j, vq, tq, N2[j], init=WT(j, 8), late=late)
+                self.shift(HA, D_BQ)
+                self.push_above(j, HA, D_BQ, N2[j], late=late)
             else:
-                self.push_self(j, vq, tq, N2[j])
+                self.push_self(j, vq, tq, N2[j], late=late)
             if j < 3:
-                self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
-        self.e("s_add_i32", S_TAU, [S_TAU, 1])
+                self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8), late=late)
         self.p.waitcnt(lgkm=0)
         if "nobar" not in self.ab:
             self.e("s_barrier")
-        self.e("s_cmp_gt_u32", (), [S_TAU, S_LAST])
+        self.e("s_sub_u32", S_TAU, [S_TAU, 1])           # S_TAU counts the remaining steps down; the borrow ends the loop
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
         if c == LV - 1:
             self.e("s_branch", (), [".LS0_%="])
@@ -442,10 +461,11 @@ class Gen(object):
                     self.e("v_pk_add_f32", tt, [tt, g[k]])
             self.e("v_rcp_f32", scale[0], [sx])
             self.e("v_rcp_f32", scale[1], [sy])
-            self.e("v_fma_f32", ex, [-sx, scale[0], 1.0])
-            self.e("v_fma_f32", ey, [-sy, scale[1], 1.0])
-            self.e("v_fma_f32", scale[0], [ex, scale[0], scale[0]])
-            self.e("v_fma_f32", scale[1], [ey, scale[1], scale[1]])
+            if self.cfg.get("newton", False):   # v_rcp_f32 is 1 ulp: one Newton step buys nothing the 1e-4 gate can see
+                self.e("v_fma_f32", ex, [-sx, scale[0], 1.0])
+                self.e("v_fma_f32", ey, [-sy, scale[1], 1.0])
+                self.e("v_fma_f32", scale[0], [ex, scale[0], scale[0]])
+                self.e("v_fma_f32", scale[1], [ey, scale[1], scale[1]])
             if norm == 0:
                 self.e("v_pk_mul_f32", t2, [tt, scale])
             else:
@@ -477,7 +497,7 @@ class Gen(object):
             if norm != 2 or self.sparse:
                 self.e("v_pk_mul_f32", g[k], [g[k], scale])
             if not nw:
-                self.e("ds_write_b64", (), [ringw, g[k]], offset=k * 1024)
+                self.e("ds_write2st64_b32", (), [ringw, g[k][0], g[k][1]], offset0=k * 4, offset1=k * 4 + 1)
         if self.hist and not self.adj:
             # the folded coefficients are also what the backward's adjoint sweep propagates with: keep a copy of the rows
             # and columns this workgroup owns (planar, [8][B*H*W])
@@ -496,14 +516,14 @@ class Gen(object):
             self.p.label(l_nown)
         hv = PEND_HIN if self.hin else PEND_BLUR
         if not nw:
-            self.e("ds_write_b64", (), [ringw, cc], offset=8 * 1024)
-            self.e("ds_write_b64", (), [ringw, hv], offset=9 * 1024)
+            self.e("ds_write2st64_b32", (), [ringw, cc[0], cc[1]], offset0=8 * 4, offset1=8 * 4 + 1)
+            self.e("ds_write2st64_b32", (), [ringw, hv[0], hv[1]], offset0=9 * 4, offset1=9 * 4 + 1)
         self.e("s_branch", (), [l_done])
         self.p.label(l_inact)
         self.mov(OUTQ[0], 0)
         self.mov(OUTQ[1], 0)
         for k in range(10):
-            self.e("ds_write_b64", (), [ringw, OUTQ.sub(0, 2)], offset=k * 1024)
+            self.e("ds_write2st64_b32", (), [ringw, OUTQ[0], OUTQ[1]], offset0=k * 4, offset1=k * 4 + 1)
         self.p.label(l_done)
 
     def issue_prepare(self, cd):
@@ -582,8 +602,9 @@ class Gen(object):
         for q in (PEND_BLUR, PEND_HIN, PEND_SP):
             self.mov(q[0], 0)
             self.mov(q[1], 0)
-        e("s_mov_b32", S_TAU, [0])
+        e("s_mov_b32", S_TAU, [S_LAST])
         e("s_mov_b32", S_ACT, [0])
+        e("s_mov_b64", VCC, [1])
         e("s_and_b32", T[2], [S_LOHI, 0xffff])
         e("s_lshr_b32", T[3], [S_LOHI, 16])
         e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
@@ -624,15 +645,20 @@ class Gen(object):
             e("s_lshl_b32", T[6], [T[6], 11])
             e("s_add_i32", T[7], [T[5], T[6]])
             e("v_add_u32", V_RB[p], [T[7], V_L16])
-        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*16
+        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*4   (ring layout [slot][plane][column][lane])
         e("s_mul_i32", T[3], [T[1], 4 * RING_SLOT])
         e("s_add_i32", T[3], [T[3], LDS_RING])
         e("s_add_i32", T[3], [T[3], S_LDSB])
-        e("v_add_u32", V_RINGR, [T[3], V_L16])
-        # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7, byte 4*xb = 512*(wv&1) + 8*lane inside a plane;
-        # V_RINGW[x] serves gamma parity x ^ (wv & 1)
-        e("v_lshlrev_b32", V_TMP, [3, V_LANE])
-        e("s_lshl_b32", T[3], [T[1], 9])
+        e("v_add_u32", V_RINGR, [T[3], V_COL4])
+        # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7; the cooking lane holds pixels 2*lane, 2*lane + 1 of half
+        # wv&1 of the row = columns 2*(lane&1), +1 of row lane 32*(wv&1) + (lane>>1): byte (lane&1)*512 + that lane * 4 inside
+        # a plane; V_RINGW[x] serves gamma parity x ^ (wv & 1)
+        e("v_and_b32", V_TMP, [1, V_LANE])
+        e("v_lshlrev_b32", V_TMP, [9, V_TMP])
+        e("v_lshrrev_b32", CK[5], [1, V_LANE])
+        e("v_lshlrev_b32", CK[5], [2, CK[5]])
+        e("v_add_u32", V_TMP, [V_TMP, CK[5]])
+        e("s_lshl_b32", T[3], [T[1], 7])
         e("v_add_u32", V_TMP, [T[3], V_TMP])
         for x in (0, 1):
             e("s_xor_b32", T[3], [T[1], x])            # gamma parity
@@ -679,23 +705,26 @@ class Gen(object):
         e("s_lshl_b32", S_QB, [S_WV, 2])
         e("s_cmp_eq_u32", (), [S_WV, 7])
         e("s_cselect_b32", S_QB, [-4, S_QB])
-        # copy this workgroup's descriptor table to LDS: 512 threads x 16 bytes per sweep
-        e("s_lshl_b32", T[3], [S_WV, 10])
-        e("v_add_u32", V_TMP, [T[3], V_L16])              # tid * 16
+        # the workgroup's descriptor table: already in LDS (written by the C++ part of the kernel before this block,
+        # cspn2d_tsw.hip: tsw_fill_table) -- or, cfg tab_in_lds = False, copied from global memory here (512 threads x 16 bytes
+        # per sweep)
         e("s_add_i32", T[3], [S_LDSB, LDS_TAB])
-        e("v_add_u32", CK[4], [T[3], V_TMP])              # LDS destination
         e("s_add_i32", S_TABB, [T[3], PADF * DESC_BYTES])
-        e("s_mov_b64", S(T[4].i, 2), [S_PLAN])
-        l_copied = self.p.newlabel("copied")
-        for i in range(TAB_MAX_ROWS // 512):
-            e("s_cmp_gt_u32", (), [S_NROWS, i * 512])
-            e("s_cbranch_scc0", (), [l_copied])
-            e("global_load_dwordx4", CK.sub(0, 4), [V_TMP, S(T[4].i, 2)])
-            e("s_add_u32", T[4], [T[4], 8192])
-            e("s_addc_u32", T[5], [T[5], 0])
-            self.p.waitcnt(vm=0)
-            e("ds_write_b128", (), [CK[4], CK.sub(0, 4)], offset=i * 8192)
-        self.p.label(l_copied)
+        if not self.cfg.get("tab_in_lds", True):
+            e("s_lshl_b32", T[2], [S_WV, 10])
+            e("v_add_u32", V_TMP, [T[2], V_L16])              # tid * 16
+            e("v_add_u32", CK[4], [T[3], V_TMP])              # LDS destination
+            e("s_mov_b64", S(T[4].i, 2), [S_PLAN])
+            l_copied = self.p.newlabel("copied")
+            for i in range(TAB_MAX_ROWS // 512):
+                e("s_cmp_gt_u32", (), [S_NROWS, i * 512])
+                e("s_cbranch_scc0", (), [l_copied])
+                e("global_load_dwordx4", CK.sub(0, 4), [V_TMP, S(T[4].i, 2)])
+                e("s_add_u32", T[4], [T[4], 8192])
+                e("s_addc_u32", T[5], [T[5], 0])
+                self.p.waitcnt(vm=0)
+                e("ds_write_b128", (), [CK[4], CK.sub(0, 4)], offset=i * 8192)
+            self.p.label(l_copied)
         self.p.waitcnt(lgkm=0)
         e("s_barrier")                               # LDS zero-fill and the table are complete
         # cooking pipeline: task n = row 4n - 1 + (wv>>1), half wv&1.  Task 0 is cooked synchronously, task 1 requested.
@@ -738,8 +767,10 @@ class Gen(object):
             self.step(c)
         self.p.label(".Lexit_%=")
         self.e("s_branch", (), [".Lend_%="])
-        for stub, back, vq in self.stubs:
+        for stub, back, vq, j in self.stubs:
             self.p.label(stub)
+            self.e("s_bitcmp1_b32", (), [S_ACT, j])
+            self.e("s_cbranch_scc1", (), [back])
             self.zero_quad(vq)
             self.e("s_branch", (), [back])
         self.p.label(".Lend_%=")

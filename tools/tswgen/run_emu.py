@@ -57,6 +57,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         if hdr[wg, 0] == 0:
             continue
         emu = Emu(prog, mem, K.LDS_BYTES)
+        fill_table(emu, tab[wg])
         for w in emu.waves:
             w.v[0] = np.arange(64, dtype=np.uint32)
             def set64(r, val):
@@ -94,7 +95,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         assert np.array_equal(np.isnan(wfb), np.isnan(wf_ref))
         assert np.nanmax(np.abs(wfb - wf_ref)) <= 1e-6 * max(1.0, np.nanmax(np.abs(wf_ref))), "folded coefficient planes"
         hb = mem[off["hist"]:off["hist"] + 23 * blur.nbytes].view(np.float32).reshape(23, B, H, W // 4, 4)
-        hb = hb[..., [0, 2, 1, 3]].reshape(23, B, 1, H, W)   # stored in register order (c0,c2,c1,c3) per 4-column group
+        hb = hb[..., [0, 2, 3, 1]].reshape(23, B, 1, H, W)   # stored in register order (c0,c3,c1,c2) per 4-column group
         worst = 0.0
         for lv in range(1, 24):
             r = O.cspn2d_oracle(g, blur, sp, lv, ["8sum", "8sum_abs", "none"][norm])
@@ -117,6 +118,13 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         print("   per wave-step: VALU %.1f SALU %.1f nop %.1f mem %.1f (steps %d)" % (
             nv / 8 / steps / n_wg, ns / 8 / steps / n_wg, nn / 8 / steps / n_wg, nm / 8 / steps / n_wg, steps))
     return err, nanmis.sum(), out, ref
+
+
+def fill_table(emu, tab_wg):
+    """the C++ part of the kernel (cspn2d_tsw.hip: tsw_fill_table) writes the workgroup's descriptor table into LDS before
+    the generated block starts; the emulator does the same with the table of tools/tswgen/plan.py"""
+    flat = np.ascontiguousarray(tab_wg, np.uint32).ravel()
+    emu.lds[K.LDS_TAB // 4:K.LDS_TAB // 4 + flat.size] = flat
 
 
 def folded_planes(g, sp, norm):
