@@ -247,9 +247,12 @@ class Emu(object):
             ndw = {"global_load_dword": 1, "global_load_dwordx2": 2, "global_load_dwordx4": 4}[o]
             idx = self.gaddr(w, ins, self.rv(w, s[0]), s[1], ndw, ex)
             regs = [("v", d[0].i + k) for k in range(ndw)]
-            for k in range(ndw):
-                self.wv(w, d[0], self.mem32[idx[:, k]], k)
-            self._pend(w, regs, w.vm_q)
+            if m.get("dummy"):   # a touch whose result nobody reads: several may be outstanding into the same register
+                w.vm_q.append([])
+            else:
+                for k in range(ndw):
+                    self.wv(w, d[0], self.mem32[idx[:, k]], k)
+                self._pend(w, regs, w.vm_q)
         elif o in VMEM_ST:
             ndw = {"global_store_dword": 1, "global_store_dwordx2": 2, "global_store_dwordx4": 4}[o]
             idx = self.gaddr(w, ins, self.rv(w, s[0]), s[2], ndw, ex)
@@ -299,6 +302,10 @@ class Emu(object):
             a, b = rs(w, s[0]), rs(w, s[1]) + w.scc
             self.ws(w, d[0], a - b)
             w.scc = int(b > a)
+        elif o == "s_min_u32":
+            a, b = rs(w, s[0]), rs(w, s[1])
+            self.ws(w, d[0], min(a, b))
+            w.scc = int(a < b)
         elif o == "s_mul_hi_u32":
             self.ws(w, d[0], (rs(w, s[0]) * rs(w, s[1])) >> 32)
         elif o == "s_mul_i32":

@@ -89,7 +89,7 @@ SMEM = {"s_load_dwordx8", "s_load_dwordx4", "s_load_dwordx2", "s_load_dword"}
 BRANCH = {"s_cbranch_scc0", "s_cbranch_scc1", "s_branch", "s_cbranch_execz", "s_cbranch_vccnz", "s_cbranch_vccz"}
 SCC_WRITERS = {"s_add_u32", "s_addc_u32", "s_subb_u32", "s_add_i32", "s_sub_i32", "s_sub_u32", "s_lshl_b32", "s_lshr_b32", "s_and_b32",
                "s_or_b32", "s_xor_b32", "s_andn2_b32", "s_and_b64", "s_or_b64", "s_andn2_b64", "s_and_saveexec_b64",
-               "s_bitcmp1_b32", "s_bitcmp0_b32", "s_ashr_i32", "s_bfe_u32"}
+               "s_bitcmp1_b32", "s_bitcmp0_b32", "s_ashr_i32", "s_bfe_u32", "s_min_u32"}
 SCC_READERS = {"s_addc_u32", "s_subb_u32", "s_cselect_b32", "s_cselect_b64", "s_cbranch_scc0", "s_cbranch_scc1"}
 
 
@@ -133,6 +133,9 @@ class I(object):
         if o == "v_mov_b32" and self.is_dpp():
             r += self.dst[0].regs()  # bound_ctrl:1 zero-fills, but keep the old value dependency conservative
         return r
+
+    def __repr__(self):
+        return self.text()
 
     def writes(self):
         if self.op == "pseudo":

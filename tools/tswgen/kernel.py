@@ -60,7 +60,10 @@ def WT(j, k):
 S_GD, S_BLUR, S_HIN, S_SP, S_OUT, S_PLAN = S(16, 2), S(18, 2), S(20, 2), S(22, 2), S(24, 2), S(26, 2)
 S_W4, S_HW4, S_LAST, S_WV = S(28), S(29), S(30), S(31)
 S_LDSB = S(15)  # LDS base address of the kernel's __shared__ block
-S_NROWS = S(14)  # descriptors in this workgroup's table (<= TAB_MAX_ROWS)
+S_NROWS = S(14)  # cfg tab_in_lds = False only: descriptors in this workgroup's table (<= TAB_MAX_ROWS)
+S_GLAST = S(14)  # cfg pf: largest row-base byte offset inside the guidance tensor a prefetch may start from (0: tensor >= 4 GB)
+V_PF, V_PFD = V(74), V(75)   # cfg pf (not with hist: V_DN): per-lane byte offset of the cache line a lane touches; dummy target
+S_PFB = S(54, 2)             # cfg pf: base address of the row being prefetched
 S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16 (one band per workgroup)
 S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
 S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(45), S(33), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
@@ -163,6 +166,8 @@ class Gen(object):
 
     def ring_read(self, dst, slot, q, **m):
         """dst quad <- coefficient quad q (or plane 8 / 9 in (c0,c3,c1,c2) order) of ring slot `slot` (0..3 of this wave's half)"""
+        if "noevlds" in self.ab:
+            return
         pa, pb = self.QUADS.get(q, (q, q))
         base = slot * (RING_SLOT // 256)
         self.e("ds_read2st64_b32", dst.sub(0, 2), [V_RINGR], offset0=base + pa * 4 + 0, offset1=base + pb * 4 + 3, **m)
@@ -340,7 +345,7 @@ class Gen(object):
                 self.ring_read(WT(0, k), 0, k, at=0.0)
         # LDS operations of a wave complete in order: everything this step reads was requested before the ten ring writes of
         # the cooking, so there is no need to wait for those
-        partial = (cook and ev != 0 and not stag and self.cfg.get("partial_wait", False)
+        partial = (cook and ev != 0 and not stag and self.cfg.get("partial_wait", True)
                    and not ({"nocookwrite", "nocookmath"} & self.ab))
         self.p.waitcnt(lgkm=10 if partial else 0)
         if ev is not None:
@@ -351,13 +356,24 @@ class Gen(object):
             self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
             loads = self.load_list()
+            if self.cfg.get("spread3", False):   # a third of the requests now, the rest in the two following steps
+                loads = loads[0::3]
             for i, (dst, voff, base) in enumerate(loads):
                 # staggered: the requests go out right here (the other wave of the SIMD keeps the VALU busy meanwhile);
                 # otherwise they are spread between the FMAs of the step
                 self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
                        at=0.0 if stag else self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
+            if self.cfg.get("pf", False):
+                self.issue_prefetch(at=0.95)
             if lab:
                 self.p.label(lab)
+        elif self.cfg.get("spread3", False) and "nocook" not in self.ab and not stag:
+            # the pending task's remaining requests: the scalar row bases (s2:3, s6:11) and the lane offsets are still in
+            # place; the data is consumed at the next step with counter % 3 == 2
+            part = self.load_list()[(c % 3) + 1::3]
+            for i, (dst, voff, base) in enumerate(part):
+                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
+                       at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / max(1, len(part)))
         # received boundary rows
         self.shift(BQ, D_BQ)
         self.push_below(3, BQ, D_BQ, N1[3])
@@ -405,7 +421,9 @@ class Gen(object):
         norm = self.norm
         l_inact, l_done = self.p.newlabel("cinact"), self.p.newlabel("cdone")
         if "nocookwait" not in self.ab:
-            self.p.waitcnt(vm=0)
+            # cfg pf: the prefetch touch issued behind the task's loads is the youngest request and may stay outstanding
+            # (loads return in order; a younger store of a retirement can only make this wait longer, never shorter)
+            self.p.waitcnt(vm=1 if self.cfg.get("pf", False) and not getattr(self, "_in_prologue", False) else 0)
         if "nocookmath" in self.ab:
             return
         l_math = self.p.newlabel("cmath")
@@ -575,13 +593,25 @@ class Gen(object):
         for dst, voff, base in items:
             self.e("global_load_dwordx2", dst, [voff, base])
 
-    def issue_task(self, cd):
+    def issue_prefetch(self, **m):
+        """cfg pf: the task after the one just requested (descriptor in S_CD) reads rows 4 further down the stream: touch its
+        cache lines now (rows of another image / beyond the share: a wasted touch, clamped into the tensor)"""
+        lead = self.cfg.get("pf_rows", 4)
+        self.e("s_mul_i32", T[6], [S_W4, lead])
+        self.e("s_add_u32", T[6], [T[6], S_CD[0]])
+        self.e("s_min_u32", T[6], [T[6], S_GLAST])
+        self.e("s_add_u32", S_PFB[0], [S_GD[0], T[6]])
+        self.e("s_addc_u32", S_PFB[1], [S_GD[1], 0])
+        self.e("global_load_dword", V_PFD, [V_PF, S_PFB], dummy=True, **m)
+
+    def issue_task(self, cd, first_third=False):
         self.issue_prepare(cd)
-        self.issue_loads(self.load_list())
+        self.issue_loads(self.load_list()[0::3] if first_third else self.load_list())
 
     # ---------------------------------------------------------------------------------- prologue
     def prologue(self):
         e = self.e
+        self._in_prologue = True
         # zero LDS: 114688 bytes / 512 threads = 14 x 16 bytes per thread
         e("v_lshlrev_b32", V_L16, [4, V_LANE])
         e("v_lshlrev_b32", V_COL4, [2, V_LANE])
@@ -687,6 +717,32 @@ class Gen(object):
                 e("s_add_i32", T[3], [T[3], S_W4])
                 e("s_add_i32", T[3], [T[3], 16])
             e("v_add_u32", V_OFFK[k], [T[3], V_OFF1])
+        if self.cfg.get("pf", False):
+            # L2 prefetch by touching: lane l = 8*k + j touches cache line j (0..4) of the half-row plane k of a future task
+            # reads (512 bytes starting up to 4 bytes before / after the row base: five 128-byte lines cover it)
+            assert not self.hist
+            e("v_lshrrev_b32", CK[5], [3, V_LANE])                 # k
+            e("v_and_b32", CK[6], [7, V_LANE])                     # j
+            e("v_cmp_lt_u32", S(T[4].i, 2), [CK[6], 4])
+            e("v_cndmask_b32", CK[6], [4, CK[6], S(T[4].i, 2)])     # min(j, 4)
+            e("v_lshlrev_b32", CK[6], [7, CK[6]])                   # * 128
+            e("v_mov_b32", V_PF, [0])
+            for k in range(8):
+                e("s_mul_i32", T[3], [S_HW4, (7 - k) if self.adj else k])
+                if self.sited:
+                    if DY[k] > 0:
+                        e("s_add_i32", T[3], [T[3], S_W4])
+                    if DY[k] < 0:
+                        e("s_sub_i32", T[3], [T[3], S_W4])
+                    if k > 0:
+                        e("s_sub_i32", T[3], [T[3], 4])
+                e("v_cmp_eq_u32", S(T[4].i, 2), [CK[5], k])
+                e("v_mov_b32", CK[8], [T[3]])
+                e("v_cndmask_b32", V_PF, [V_PF, CK[8], S(T[4].i, 2)])
+            e("v_add_u32", V_PF, [V_PF, CK[6]])
+            e("s_lshl_b32", T[3], [T[1], 9])                        # half * 512
+            e("v_add_u32", V_PF, [T[3], V_PF])
+            e("v_mov_b32", V_PFD, [0])
         if self.hist:
             e("s_and_b32", T[2], [S_LOHI, 0xffff])
             e("s_lshl_b32", T[2], [T[2], 2])
@@ -750,12 +806,15 @@ class Gen(object):
         self.cook_pending(V_TMP)
         self.p.waitcnt(lgkm=0)
         self.take_cook()
-        self.issue_task(S_CD)
+        self.issue_task(S_CD, first_third=self.cfg.get("spread3", False))   # the loop's first two steps request the rest
+        if self.cfg.get("pf", False):
+            self.issue_prefetch()
         e("s_add_i32", S_PQ, [S_PQ, 4])
         if l_late:
             self.p.label(l_late)
         self.p.waitcnt(lgkm=0)
         e("s_barrier")
+        self._in_prologue = False
         for w in range(NW):
             c0 = (LV - 3 * w) % LV
             e("s_cmp_eq_u32", (), [S_WV, w])

@@ -69,7 +69,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             set64(K.S_SP, off["sp"])
             set64(K.S_OUT, off["out"])
             set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16)
-            w.s[K.S_NROWS.i] = tab.shape[1]
+            w.s[K.S_NROWS.i] = max(0, g.nbytes - 7 * 4 * H * W - 2 * 4 * W)   # S_GLAST (cfg pf); S_NROWS when tab_in_lds = False
             w.s[K.S_LOHI.i] = int(hdr[wg, 2])
             if hist:
                 set64(K.S_HIST, off["hist"])
