@@ -49,6 +49,9 @@ def parse():
                     help="seconds of untimed launches before the counted warm-up (lets the shader clock settle: the first "
                          "few dozen launches of a process run ~20 %% slower); outside the timed region, reported as prewarm_s")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--pmc-calib", action="store_true",
+                    help="profiling runs: one torch elementwise kernel over the depth batch before the loop (known byte count, "
+                         "calibrates FETCH_SIZE / WRITE_SIZE in the same rocprofv3 trace)")
     ap.add_argument("--no-broadcast", action="store_true")
     return ap.parse_args()
 
@@ -256,6 +259,9 @@ def main():
                                          stream.cuda_stream)
         _lib.check(rc, "cspn2d_forward_f32_algo")
 
+    if a.pmc_calib:
+        _calib = h * 1.0   # reads and writes B*H*W*4 bytes
+        del _calib
     # clock pre-warm: untimed full-work launches for a fixed wall time (outside the timed region)
     prewarm_s, prewarm_launches = 0.0, 0
     if a.prewarm_s > 0:

@@ -17,10 +17,14 @@ from .isa import Prog, V, S, EXEC, VCC, schedule, check_hazards, expand_pseudos
 NW, NSLOT, LV = 8, 4, 24
 PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
 DESC_BYTES = 16              # goff_lo, goff_hi, boff, flags | lo << 8 | hi << 20
-LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 10240
-LDS_TAB = LDS_RING + 8 * RING_SLOT   # the workgroup's row-descriptor table, copied from global memory by the prologue
-TAB_MAX_ROWS = 3072
+# ring of cooked rows: 8 slots x 64 lane records; a record = [plane 0..9][column 0..3] floats + 2 pad = 42 dwords, so that the
+# cooking lanes (two per record, 8 adjacent bytes each) and the reading lanes (stride 42 dwords) are free of bank conflicts
+RING_REC = 168
+LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 64 * RING_REC
+LDS_TAB = LDS_RING + 8 * RING_SLOT   # the workgroup's row-descriptor table (written by the C++ part of the kernel)
+TAB_MAX_ROWS = 2816
 LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES   # 160 KB
+assert LDS_BYTES <= 163840
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
 
@@ -30,7 +34,8 @@ F_ACTIVE, F_UP, F_DN, F_FIRST, F_LAST, F_OWNED, F_PLAIN = 0, 1, 2, 3, 4, 5, 6  #
 # ---- VGPR map ----
 V_LANE, V_COL4, V_L16 = V(0), V(1), V(2)
 V_WR, V_RT, V_RB = [V(3), V(4)], [V(5), V(6)], [V(7), V(8)]
-V_RINGR = V(9)
+V_RINGR = V(9)              # ring record of this lane in slot 0 of the wave's half of the ring
+V_RINGE = [V(0), V(1)]      # (after the prologue) the same record in the slot of the current event / of the slot before it
 V_RINGW = [V(10), V(11)]
 V_OFFK = [V(12 + k) for k in range(8)]
 V_OFF1 = V(20)
@@ -161,17 +166,16 @@ class Gen(object):
         self.fma(ay, WT(j, 4).sub(2, 2), X, ay, late=late)
         self.fma(ax, WT(j, 4).sub(0, 2), D, ax, late=late)
 
-    # ring: [slot][plane 0..9][column 0..3][lane 0..63] floats; plane 8 = c', plane 9 = H0
+    # ring: [slot][lane 0..63][plane 0..9][column 0..3] floats (+ 2 pad per lane record); plane 8 = c', plane 9 = H0
     QUADS = {0: (0, 2), 2: (2, 0), 3: (3, 4), 4: (4, 3), 5: (5, 7), 7: (7, 5)}   # q -> (plane of elements 0,2 ; of elements 1,3)
 
-    def ring_read(self, dst, slot, q, **m):
-        """dst quad <- coefficient quad q (or plane 8 / 9 in (c0,c3,c1,c2) order) of ring slot `slot` (0..3 of this wave's half)"""
+    def ring_read(self, dst, addr, q, **m):
+        """dst quad <- coefficient quad q (or plane 8 / 9 in (c0,c3,c1,c2) order) of the lane's ring record at addr"""
         if "noevlds" in self.ab:
             return
         pa, pb = self.QUADS.get(q, (q, q))
-        base = slot * (RING_SLOT // 256)
-        self.e("ds_read2st64_b32", dst.sub(0, 2), [V_RINGR], offset0=base + pa * 4 + 0, offset1=base + pb * 4 + 3, **m)
-        self.e("ds_read2st64_b32", dst.sub(2, 2), [V_RINGR], offset0=base + pa * 4 + 1, offset1=base + pb * 4 + 2, **m)
+        self.e("ds_read2_b32", dst.sub(0, 2), [addr], offset0=pa * 4 + 0, offset1=pb * 4 + 3, **m)
+        self.e("ds_read2_b32", dst.sub(2, 2), [addr], offset0=pa * 4 + 1, offset1=pb * 4 + 2, **m)
 
     def zero_quad(self, q):
         for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
@@ -236,7 +240,7 @@ class Gen(object):
 
     def inject(self, j, vq):
         for k in self.late_planes(j):
-            self.ring_read(WT(j, k), j, k, at=0.0)
+            self.ring_read(WT(j, k), V_RINGE[0], k, at=0.0)
         for i in (1, 0, 2, 3):   # the DPP sources first
             self.mov(vq[i], HN[i])
         self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
@@ -282,6 +286,34 @@ class Gen(object):
         self.e("pseudo", (), (), expand=exp, reads=[("s", S_ACT.i), ("vcc", 0), ("vcc", 1)] + vq.regs(), writes=[("scc", 0)] + vq.regs())
         self.stubs.append((stub, back, vq, j))
 
+    # ---- cfg trace (timing instrumentation, tools/tsw_trace.py): six s_memtime stamps per step at points that are fences of
+    # the schedule anyway, written out per wave and step after the barrier.  Not for hist / hin variants (their registers).
+    TRACE_REGS = [S(84, 2), S(86, 2), S(88, 2), S(90, 2), S(96, 2), S(98, 2)]
+    TRACE_BYTES = 32   # per wave and step: the six stamps (low dwords), the variant number, spare
+
+    def probe(self, k):
+        if self.cfg.get("trace", False):
+            r = self.TRACE_REGS[k]
+            self.e("raw", (), ["s_memtime s[%d:%d]" % (r.i, r.i + 1)])
+
+    def trace_flush(self, c, cook):
+        if not self.cfg.get("trace", False):
+            return
+        e = self.e
+        e("raw", (), ["s_waitcnt lgkmcnt(0)"])
+        for k, r in enumerate(self.TRACE_REGS):
+            if k == 1 and not cook:
+                e("raw", (), ["v_writelane_b32 v74, s%d, 1" % self.TRACE_REGS[0].i])   # no cooking in this step: stamp 1 = stamp 0
+            else:
+                e("raw", (), ["v_writelane_b32 v74, s%d, %d" % (r.i, k)])
+        e("raw", (), ["s_movk_i32 s0, %d" % c])
+        e("raw", (), ["v_writelane_b32 v74, s0, 6"])
+        e("raw", (), ["s_mov_b64 exec, 0xff"])
+        e("raw", (), ["global_store_dword v75, v74, s[26:27]"])
+        e("raw", (), ["s_mov_b64 exec, -1"])
+        e("raw", (), ["s_add_u32 s26, s26, %d" % (NW * self.TRACE_BYTES)])
+        e("raw", (), ["s_addc_u32 s27, s27, 0"])
+
     def tail(self, c, skip_above1=False):
         """the part of step c nobody else waits for (slot 0's pushes after its value was published); emitted at the top of
         the following step, between the boundary-row reads and their wait.  skip_above1: slot 1 is replaced in the
@@ -318,56 +350,63 @@ class Gen(object):
             self.e("s_cbranch_scc0" if cook_hi else "s_cbranch_scc1", (), [lab])
             return lab
         self.p.label(".LS%d_%%=" % c)
-        # ---- top: everything that travels through LDS is requested first
+        self.probe(0)
+        assert not stag, "the stagger option was dropped (measured 1 % slower)"
+        partial = self.cfg.get("partial_wait", True) and not self.cfg.get("trace", False)
+        # ---- top: everything that travels through LDS is requested first; what the chain needs at once comes first, because
+        # the LDS operations of a wave complete in order and the waits below count the requests that may stay outstanding
         if "nolds" not in self.ab:
             self.e("ds_read_b128", BQ, [V_RB[p]], at=0.0)
             self.e("ds_read_b128", TQ, [V_RT[p]], at=0.0)
-        if ev is not None:
-            self.fetch_event(ev)
-            self.ring_read(HN, ev, 9, at=0.0)
-            if ev > 0:
-                self.ring_read(HA, ev - 1, 9, at=0.0)
-            if ev > 0:
-                for k in self.early_planes(ev):
-                    self.ring_read(WT(ev, k), ev, k, at=0.0)
         if cook:
             self.fetch_cook()
-        loads = []
+        n_after = 0   # LDS requests behind those the mid-step wait needs
+        if ev is not None:
+            self.fetch_event(ev)
+            n_after += 2
+            self.e("v_add_u32", V_RINGE[0], [ev * RING_SLOT, V_RINGR])
+            self.ring_read(HN, V_RINGE[0], 9, at=0.0)
+            n_after += 2
+            if ev > 0:
+                self.e("v_add_u32", V_RINGE[1], [(ev - 1) * RING_SLOT, V_RINGR])
+                self.ring_read(HA, V_RINGE[1], 9, at=0.0)
+                for k in self.early_planes(ev):
+                    self.ring_read(WT(ev, k), V_RINGE[0], k, at=0.0)
+                n_after += 2 + 2 * len(self.early_planes(ev))
+            if "noevlds" in self.ab:
+                n_after = 2
+        loads, deferred = [], []
         if cook:
-            # normalise + fold the pending task while the boundary rows arrive
-            lab = guard()
-            self.cook_pending(V_RINGW[g])
-            if lab:
-                self.p.label(lab)
+            # normalise + fold the pending task while the boundary rows arrive (c' and H0 go to the ring at once, the eight
+            # coefficient planes from the main region below)
+            deferred = self.cook_pending(V_RINGW[g])
+            if not ({"nocookwrite", "nocookmath"} & self.ab):
+                n_after += 2
+            self.probe(1)
         self.tail((c - 1) % LV, skip_above1=(ev == 1))
         if ev == 0:  # slot 0's self taps were still needed by the deferred tail
             for k in self.early_planes(0):
-                self.ring_read(WT(0, k), 0, k, at=0.0)
-        # LDS operations of a wave complete in order: everything this step reads was requested before the ten ring writes of
-        # the cooking, so there is no need to wait for those
-        partial = (cook and ev != 0 and not stag and self.cfg.get("partial_wait", True)
-                   and not ({"nocookwrite", "nocookmath"} & self.ab))
-        self.p.waitcnt(lgkm=10 if partial else 0)
-        if ev is not None:
+                self.ring_read(WT(0, k), V_RINGE[0], k, at=0.0)
+            if "noevlds" not in self.ab:
+                n_after += 2 * len(self.early_planes(0))
+        self.p.waitcnt(lgkm=min(n_after, 15) if partial else 0)
+        self.probe(2)
+        if ev is not None and not partial:
             self.take_event()
         if cook:
-            lab = guard()
             self.take_cook()
             self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
+            self.ring_writes(deferred, self.cfg.get("rw_at", 0.02), self.cfg.get("rw_at", 0.02) + self.cfg.get("rw_span", 0.5))
             loads = self.load_list()
             if self.cfg.get("spread3", False):   # a third of the requests now, the rest in the two following steps
                 loads = loads[0::3]
             for i, (dst, voff, base) in enumerate(loads):
-                # staggered: the requests go out right here (the other wave of the SIMD keeps the VALU busy meanwhile);
-                # otherwise they are spread between the FMAs of the step
                 self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
-                       at=0.0 if stag else self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
+                       at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
             if self.cfg.get("pf", False):
                 self.issue_prefetch(at=0.95)
-            if lab:
-                self.p.label(lab)
-        elif self.cfg.get("spread3", False) and "nocook" not in self.ab and not stag:
+        elif self.cfg.get("spread3", False) and "nocook" not in self.ab:
             # the pending task's remaining requests: the scalar row bases (s2:3, s6:11) and the lane offsets are still in
             # place; the data is consumed at the next step with counter % 3 == 2
             part = self.load_list()[(c % 3) + 1::3]
@@ -384,6 +423,9 @@ class Gen(object):
             vq = N1[j]
             tq = D_SLOT.get(j)
             if ev == j:
+                if partial:   # the descriptors and the ring planes of the event were requested at the top of the step
+                    self.p.waitcnt(lgkm=0)
+                    self.take_event()
                 self.retire(j, vq)
                 self.inject(j, vq)
             elif "noact" not in self.ab:
@@ -406,9 +448,13 @@ class Gen(object):
                 self.push_self(j, vq, tq, N2[j], late=late)
             if j < 3:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8), late=late)
+        self.probe(3)
         self.p.waitcnt(lgkm=0)
+        self.probe(4)
         if "nobar" not in self.ab:
             self.e("s_barrier")
+        self.probe(5)
+        self.trace_flush(c, cook)
         self.e("s_sub_u32", S_TAU, [S_TAU, 1])           # S_TAU counts the remaining steps down; the borrow ends the loop
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
         if c == LV - 1:
@@ -425,7 +471,7 @@ class Gen(object):
             # (loads return in order; a younger store of a retirement can only make this wait longer, never shorter)
             self.p.waitcnt(vm=1 if self.cfg.get("pf", False) and not getattr(self, "_in_prologue", False) else 0)
         if "nocookmath" in self.ab:
-            return
+            return []
         l_math = self.p.newlabel("cmath")
         self.e("s_bitcmp1_b32", (), [S_PFLAGS, F_PLAIN])   # most rows: nothing to patch
         self.e("s_cbranch_scc1", (), [l_math])
@@ -511,11 +557,12 @@ class Gen(object):
             self.e("v_pk_mul_f32", t2, [mm, h0])
             self.fma(cc, om, cc, t2, keep=True)
         nw = "nocookwrite" in self.ab
+        deferred = []   # the eight coefficient planes are written from the caller's main region, between its FMAs
         for k in range(8):
             if norm != 2 or self.sparse:
                 self.e("v_pk_mul_f32", g[k], [g[k], scale])
             if not nw:
-                self.e("ds_write2st64_b32", (), [ringw, g[k][0], g[k][1]], offset0=k * 4, offset1=k * 4 + 1)
+                deferred.append((ringw, g[k], k * 16))
         if self.hist and not self.adj:
             # the folded coefficients are also what the backward's adjoint sweep propagates with: keep a copy of the rows
             # and columns this workgroup owns (planar, [8][B*H*W])
@@ -534,15 +581,25 @@ class Gen(object):
             self.p.label(l_nown)
         hv = PEND_HIN if self.hin else PEND_BLUR
         if not nw:
-            self.e("ds_write2st64_b32", (), [ringw, cc[0], cc[1]], offset0=8 * 4, offset1=8 * 4 + 1)
-            self.e("ds_write2st64_b32", (), [ringw, hv[0], hv[1]], offset0=9 * 4, offset1=9 * 4 + 1)
+            self.e("ds_write_b64", (), [ringw, cc], offset=8 * 16)
+            self.e("ds_write_b64", (), [ringw, hv], offset=9 * 16)
         self.e("s_branch", (), [l_done])
         self.p.label(l_inact)
         self.mov(OUTQ[0], 0)
         self.mov(OUTQ[1], 0)
-        for k in range(10):
-            self.e("ds_write2st64_b32", (), [ringw, OUTQ[0], OUTQ[1]], offset0=k * 4, offset1=k * 4 + 1)
+        for k in range(8):
+            self.mov(g[k][0], 0)
+            self.mov(g[k][1], 0)
+        if not nw:
+            for k in (8, 9):
+                self.e("ds_write_b64", (), [ringw, OUTQ.sub(0, 2)], offset=k * 16)
         self.p.label(l_done)
+        return deferred
+
+    def ring_writes(self, deferred, lo=None, hi=None):
+        for i, (addr, reg, off) in enumerate(deferred):
+            m = {} if lo is None else {"at": lo + (hi - lo) * i / max(1, len(deferred))}
+            self.e("ds_write_b64", (), [addr, reg], offset=off, **m)
 
     def issue_prepare(self, cd):
         """scalar side of a task request: flags and the base addresses of its rows (kept in s0..s11 while the loads are
@@ -612,17 +669,9 @@ class Gen(object):
     def prologue(self):
         e = self.e
         self._in_prologue = True
-        # zero LDS: 114688 bytes / 512 threads = 14 x 16 bytes per thread
+        # LDS below the descriptor table (boundary rows, ring) was zeroed by the C++ part of the kernel (cspn2d_tsw.hip)
         e("v_lshlrev_b32", V_L16, [4, V_LANE])
         e("v_lshlrev_b32", V_COL4, [2, V_LANE])
-        e("s_lshl_b32", T[0], [S_WV, 10])
-        e("s_add_i32", T[0], [T[0], S_LDSB])
-        e("v_add_u32", V_TMP, [T[0], V_L16])  # wave*1024 + lane*16 : 8 KB per sweep
-        for k in range(4):
-            self.mov(CK[k], 0)
-        e("v_add_u32", CK[4], [0x10000, V_TMP])
-        for i in range(14):
-            e("ds_write_b128", (), [V_TMP if i < 8 else CK[4], CK.sub(0, 4)], offset=(i & 7) * 8192)
         # state
         for r in range(ACC_BASE, WT_BASE + 144):
             self.mov(V(r), 0)
@@ -675,20 +724,21 @@ class Gen(object):
             e("s_lshl_b32", T[6], [T[6], 11])
             e("s_add_i32", T[7], [T[5], T[6]])
             e("v_add_u32", V_RB[p], [T[7], V_L16])
-        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*4   (ring layout [slot][plane][column][lane])
+        # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*RING_REC
         e("s_mul_i32", T[3], [T[1], 4 * RING_SLOT])
         e("s_add_i32", T[3], [T[3], LDS_RING])
         e("s_add_i32", T[3], [T[3], S_LDSB])
-        e("v_add_u32", V_RINGR, [T[3], V_COL4])
+        e("v_mul_u32_u24", V_RINGR, [RING_REC, V_LANE])
+        e("v_add_u32", V_RINGR, [T[3], V_RINGR])
         # ring write addresses: slot(g) = (4g + (wv>>1) - 1) & 7; the cooking lane holds pixels 2*lane, 2*lane + 1 of half
-        # wv&1 of the row = columns 2*(lane&1), +1 of row lane 32*(wv&1) + (lane>>1): byte (lane&1)*512 + that lane * 4 inside
-        # a plane; V_RINGW[x] serves gamma parity x ^ (wv & 1)
+        # wv&1 of the row = columns 2*(lane&1), +1 of row lane 32*(wv&1) + (lane>>1): byte that lane * RING_REC + (lane&1)*8
+        # inside a slot (+ plane * 16); V_RINGW[x] serves gamma parity x ^ (wv & 1)
         e("v_and_b32", V_TMP, [1, V_LANE])
-        e("v_lshlrev_b32", V_TMP, [9, V_TMP])
+        e("v_lshlrev_b32", V_TMP, [3, V_TMP])
         e("v_lshrrev_b32", CK[5], [1, V_LANE])
-        e("v_lshlrev_b32", CK[5], [2, CK[5]])
+        e("v_mul_u32_u24", CK[5], [RING_REC, CK[5]])
         e("v_add_u32", V_TMP, [V_TMP, CK[5]])
-        e("s_lshl_b32", T[3], [T[1], 7])
+        e("s_mul_i32", T[3], [T[1], 32 * RING_REC])
         e("v_add_u32", V_TMP, [T[3], V_TMP])
         for x in (0, 1):
             e("s_xor_b32", T[3], [T[1], x])            # gamma parity
@@ -803,7 +853,7 @@ class Gen(object):
             l_late = self.p.newlabel("late")
             e("s_bitcmp1_b32", (), [S_WV, 2])
             e("s_cbranch_scc1", (), [l_late])
-        self.cook_pending(V_TMP)
+        self.ring_writes(self.cook_pending(V_TMP))
         self.p.waitcnt(lgkm=0)
         self.take_cook()
         self.issue_task(S_CD, first_third=self.cfg.get("spread3", False))   # the loop's first two steps request the rest
@@ -814,6 +864,12 @@ class Gen(object):
             self.p.label(l_late)
         self.p.waitcnt(lgkm=0)
         e("s_barrier")
+        if self.cfg.get("trace", False):
+            assert not self.hist and not self.hin and not self.cfg.get("pf", False)
+            e("s_mul_i32", T[3], [S_WV, self.TRACE_BYTES])
+            e("v_lshlrev_b32", V(75), [2, V_LANE])
+            e("v_add_u32", V(75), [T[3], V(75)])
+            e("v_mov_b32", V(74), [0])
         self._in_prologue = False
         for w in range(NW):
             c0 = (LV - 3 * w) % LV
