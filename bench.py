@@ -126,22 +126,24 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
 
 def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
     """BASELINE config 5: 3x3x3 propagation, 12 iterations, 32x160x608 volume, batch 4 per GPU, gates normalised by the
-    caller and used as given (the fluid.layers.affinity_propagate contract, reference cspn_paddle/demo.py:41-52): one
-    step3d_direct_kernel launch per iteration, each moving exactly the algorithmic bytes of a single step."""
+    caller and used as given (the fluid.layers.affinity_propagate contract, reference cspn_paddle/demo.py:41-52).
+    --algo auto / fused: the persistent kernel (gates resident in registers across all steps: one pass over the 104 B/voxel
+    gate tensor per forward); --algo stepwise: one step3d_direct_kernel launch per iteration."""
     B, D, H, W, n_iter = (4 if a.batch_per_gpu == 64 else a.batch_per_gpu), 32, 160, 608, 12
     gen = torch.Generator(device=dev).manual_seed(5000 + rank)
     g = torch.rand(B, 26, D, H, W, generator=gen, device=dev)
     g /= g.sum(1, keepdim=True)
     h = torch.rand(B, 1, D, H, W, generator=gen, device=dev)
     out = torch.empty_like(h)
-    ws_bytes = lib.cspn3d_workspace_bytes(B, D, H, W, n_iter)
+    norm = _lib.NORM_TYPES["none"]
+    algo3 = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 2}[a.algo]
+    ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, n_iter, norm, 0)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
-    norm = _lib.NORM_TYPES["none"]
 
     def step():
-        _lib.check(lib.cspn3d_forward_f32(g.data_ptr(), h.data_ptr(), None, out.data_ptr(), B, D, H, W, n_iter, norm,
-                                          ws.data_ptr(), ws_bytes, stream.cuda_stream), "cspn3d_forward_f32")
+        _lib.check(lib.cspn3d_forward_f32_algo(g.data_ptr(), h.data_ptr(), None, out.data_ptr(), B, D, H, W, n_iter, norm, algo3,
+                                               ws.data_ptr(), ws_bytes, stream.cuda_stream), "cspn3d_forward_f32_algo")
 
     steps, warmup = min(a.steps, 60), min(a.warmup, 20)
     for _ in range(warmup):
@@ -160,29 +162,51 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms_avg = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
+    # parity of what the timed launches left in `out`: the other 3D path on every voxel + the oracle on a sub-volume
+    parity = None
+    if not a.no_parity_check:
+        other = torch.empty_like(out)
+        _lib.check(lib.cspn3d_forward_f32_algo(g.data_ptr(), h.data_ptr(), None, other.data_ptr(), B, D, H, W, n_iter, norm,
+                                               1 if algo3 != 1 else 0, ws.data_ptr(), ws_bytes, stream.cuda_stream), "other 3D path")
+        torch.cuda.synchronize()
+        err = float((out - other).abs().max() / other.abs().max())
+        parity = {"ok": bool(err <= 1e-5 and torch.isfinite(out).all()), "max_rel_diff_between_3d_paths": err,
+                  "pinned": False, "note": "the Paddle op's source is not in the reference tree: parity unpinned; the two HIP "
+                  "paths are compared on every voxel, tests/ compare with oracle/ on sub-volumes"}
     if dist is not None:
         t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms_avg = float(t[0]), float(t[1])
     if rank == 0:
         vox = B * D * H * W
-        launch_ms = dev_ms_avg / n_iter            # n_iter identical launches per forward, nothing else on the stream
-        achieved = vox * 112 / (launch_ms * 1e-3) / 1e9
+        persistent = algo3 != 1
+        fwd_frac = vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if persistent:
+            roof = {"bound": "hbm", "kernel": "cspn3d_persistent_kernel (one launch per forward: gates read once, %d steps on chip)" % n_iter,
+                    "achieved": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(fwd_frac, 4), "traffic": None, "algorithmic_bytes_per_launch": vox * 112,
+                    "device_ms_per_launch": round(dev_ms_avg, 4), "whole_forward_frac": round(fwd_frac, 4),
+                    "note": "algorithmic bytes = 26 gates + value in, value out = 112 B/voxel ONCE per forward (SURVEY 8d)"}
+        else:
+            launch_ms = dev_ms_avg / n_iter
+            roof = {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
+                    "achieved": round(vox * 112 / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(vox * 112 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
+                    "whole_forward_frac": round(fwd_frac, 4),
+                    "note": "per launch = one propagation step (112 B/voxel); whole_forward_frac prices all %d iterations "
+                            "against a single pass over the inputs" % n_iter}
         res = {
             "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
             "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (uniform gates normalised over the 26 channels, uniform feature volume; generated on device)",
+            "parity_checked": parity,
             "config": {"workload": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 volume, batch %d per GPU" % B,
                        "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none (gates pre-normalised by the caller)",
+                       "algo": "persistent" if persistent else "stepwise",
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
-                         "whole_forward_frac": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "per launch = one propagation step (26 gates + value in, value out = 112 B/voxel); "
-                                 "whole_forward_frac prices all 12 iterations against a single pass over the inputs"},
+            "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             from oracle import cspn3d_oracle, oracle_threads, set_oracle_threads

@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
 ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
+ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
 ABI_VERSION = 1
 
 _lib = None
@@ -74,10 +75,20 @@ def load():
     lib.cspn_unpool_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
     lib.cspn_unpool_backward_f32.restype = c_int
     lib.cspn_unpool_backward_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
+    lib.cspn_sparse_sample_workspace_bytes.restype = c_size_t
+    lib.cspn_sparse_sample_workspace_bytes.argtypes = [c_size_t]
+    lib.cspn_sparse_sample_f32.restype = c_int
+    lib.cspn_sparse_sample_f32.argtypes = [vp, vp, c_size_t, c_size_t, c_int, c_int, ctypes.c_ulonglong, vp, c_size_t, vp]
     lib.cspn3d_workspace_bytes.restype = c_size_t
     lib.cspn3d_workspace_bytes.argtypes = [c_int] * 5
     lib.cspn3d_forward_f32.restype = c_int
     lib.cspn3d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    lib.cspn3d_workspace_bytes_ex.restype = c_size_t
+    lib.cspn3d_workspace_bytes_ex.argtypes = [c_int] * 7
+    lib.cspn3d_forward_f32_algo.restype = c_int
+    lib.cspn3d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 7 + [vp, c_size_t, vp]
+    lib.cspn_debug_3d_persistent_error.restype = c_int
+    lib.cspn_debug_3d_persistent_error.argtypes = [vp] + [c_int] * 4
     v = lib.cspn_abi_version()
     if v != ABI_VERSION:
         raise CspnError("cspn_amd: ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))

@@ -1,0 +1,291 @@
+// cspn3d_persistent.hip -- n_iter chained 3x3x3 propagation steps (reference cspn_paddle/demo.py:41-43,50-52: one
+// fluid.layers.affinity_propagate call per step, gates normalised by the caller and used as given) with the 26 gates of a
+// voxel read from HBM ONCE per forward instead of once per step.
+//
+// Why a persistent kernel: a step needs all 26 gates of every voxel (104 B/voxel); fusing steps means keeping them on chip.
+// One CU holds 4096 voxels' gates in its register file (512 threads x 8 voxels x 26 floats = 416 KB of the 512 KB), the
+// whole device about one million: a "chunk" -- an x-slab of one volume, cut with n_iter halo voxels on each interior side
+// -- is loaded once, all n_iter steps run on it while the gates stay in registers, then the next chunk is taken.  Between
+// steps only the VALUES move (4 B/voxel): every workgroup writes its tile's new level to a scratch volume with memory-side
+// (sc1) stores, raises a per-tile step flag, waits for the flags of its up to 26 neighbour tiles and reads its one-voxel halo
+// shell back with sc1 loads -- no fences, no grid-wide barrier inside a chunk (tools/ubench_gridsync.hip: 4.5 us per step
+// for this exchange vs 10.3 us for a device-wide counter barrier).  Garbage from the cut faces of a chunk travels one voxel
+// per step and stays inside the halo.  HBM traffic = 112 B/voxel x (1 + 2*n_iter / owned x-extent) once, independent of
+// n_iter, plus 8 B/voxel/step of L2/MALL-level value traffic.
+//
+// Only the Paddle contract (norm NONE, no sparse mask, W % 4 == 0, 16-byte aligned tensors); other modes run
+// cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
+#include "cspn_common.h"
+
+namespace cspn {
+namespace {
+
+constexpr int TZ = 8, TY = 8, TX = 64;          // tile = 4096 voxels, 8 consecutive x per thread
+constexpr int NTP = 512;                          // 2 waves per SIMD: 256 registers per thread, 208 of them gates
+constexpr int LZ = TZ + 2, LY = TY + 2, LXU = TX + 2, LX = 68;   // LDS tile with halo, rows padded to 68 floats
+constexpr int LTILE = LZ * LY * LX;              // 6800 floats per level buffer
+constexpr unsigned SPIN_MAX = 1u << 18;
+constexpr int MAX_WG = 256;
+
+struct Geo3 {
+    int B, D, H, W, n_iter, halo;
+    int tz, ty, cx;          // tiles along z, y (whole extent) and along x per chunk
+    int S;                   // owned x-extent of a chunk
+    int nchunk;              // chunks per volume
+    int n_wg;                // workgroups launched (>= tz * ty * cx)
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st16_sc1(float* p, float4 v) {
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
+// device-wide barrier between chunks: workgroups of one XCD (id % 8) count on an XCD-local counter with L2-level atomics,
+// the last arriver of each XCD counts on the device counter, everybody polls that one (tools/ubench_gridsync.hip mode 4)
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned epoch, int n_wg, unsigned* err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned x = blockIdx.x & 7, per_x = (unsigned)(n_wg + 7 - (int)x) / 8;
+        const unsigned old = __hip_atomic_fetch_add(bar + 64 * (x + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old + 1) % per_x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)(n_wg < 8 ? n_wg : 8);
+        unsigned n = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++n > SPIN_MAX) { *err = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
+                                                                 float* __restrict__ out, float* __restrict__ scratch,
+                                                                 unsigned* __restrict__ sync, Geo3 g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * LTILE];
+    __shared__ int s_bail;
+    unsigned* flags = sync;                  // [MAX_WG] per-tile step flags
+    unsigned* bar = sync + MAX_WG;           // [64 * 9] barrier counters (one cache line each)
+    unsigned* err = sync + MAX_WG + 64 * 9;  // [1]
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
+    float* P[2] = {scratch, scratch + total};
+    const int tiles = g.tz * g.ty * g.cx;
+    const bool have_tile = wg < tiles;
+    const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
+    const int lx = (tid & 7) * 8, ly = (tid >> 3) & 7, lz = tid >> 6;   // 8 consecutive x per thread
+    if (tid == 0) s_bail = 0;
+    // neighbour tile of this thread (threads 0..25), -1: none inside the chunk window
+    int nb = -1;
+    if (tid < 26 && have_tile) {
+        const int c = tid < 13 ? tid : tid + 1;
+        const int nz = iz + c / 9 - 1, ny = iy + (c / 3) % 3 - 1, nx = ix + c % 3 - 1;
+        if (nz >= 0 && nz < g.tz && ny >= 0 && ny < g.ty && nx >= 0 && nx < g.cx) nb = (nz * g.ty + ny) * g.cx + nx;
+    }
+    unsigned epoch = 0;
+    for (int b = 0; b < g.B; ++b) {
+        for (int c = 0; c < g.nchunk; ++c) {
+            const unsigned round = (unsigned)(b * g.nchunk + c);
+            if (have_tile) {
+                const int ox0 = c * g.S, ox1 = min(g.W, ox0 + g.S);     // owned columns of the chunk
+                const int wx0 = ox0 - g.halo;                            // window start (may be negative)
+                const int z0 = iz * TZ, y0 = iy * TY, x0 = wx0 + ix * TX;
+                // ---- the 26 gates of the thread's eight voxels: read once, kept in registers for all steps
+                float4 w[26][2];
+                {
+                    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+                    const bool in_zy = z < g.D && y < g.H;
+                    const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
+                    const float* gb = gate + (size_t)b * 26 * V + ((size_t)z * g.H + y) * g.W + x;
+#pragma unroll
+                    for (int k = 0; k < 26; ++k) {
+                        v4f t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+                        if (in0) t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gb + (size_t)k * V));
+                        if (in1) t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gb + (size_t)k * V + 4));
+                        w[k][0] = make_float4(t0.x, t0.y, t0.z, t0.w);
+                        w[k][1] = make_float4(t1.x, t1.y, t1.z, t1.w);
+                    }
+                }
+                // ---- level 0 of the tile and its halo shell into both LDS buffers (outside the volume: 0, for good; outside
+                // the chunk window: the level-0 value, any finite number will do there)
+                for (int i = tid; i < LZ * LY * LXU; i += NTP) {
+                    const int pz = i / (LY * LXU), r = i - pz * (LY * LXU), py = r / LXU, px = r - py * LXU;
+                    const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
+                    float v = 0.f;
+                    if (vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W)
+                        v = feat[(size_t)b * V + ((size_t)vz * g.H + vy) * g.W + vx];
+                    lds[(pz * LY + py) * LX + px] = v;
+                    lds[LTILE + (pz * LY + py) * LX + px] = v;
+                }
+                __syncthreads();
+                for (int it = 1; it <= g.n_iter; ++it) {
+                    // the 208 gate registers leave no room for loop-invariant addresses: everything below is recomputed from
+                    // tid_ each step (a handful of integer instructions) instead of being kept live across the loop
+                    int tid_ = tid;
+                    asm volatile("" : "+v"(tid_));
+                    const int lx = (tid_ & 7) * 8, ly = (tid_ >> 3) & 7, lz = tid_ >> 6;
+                    const float* cur = lds + ((it - 1) & 1) * LTILE;
+                    float* nxt = lds + (it & 1) * LTILE;
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int n = 0; n < 9; ++n) {   // the 9 neighbour rows (dz, dy); three x-taps each
+                        const int dz = 1 - n / 3, dy = 1 - n % 3;
+                        const float* row = cur + ((lz + 1 + dz) * LY + (ly + 1 + dy)) * LX + lx;
+                        const float4 a0 = *reinterpret_cast<const float4*>(row);        // x-1 .. x+2
+                        const float4 a1 = *reinterpret_cast<const float4*>(row + 4);    // x+3 .. x+6
+                        const float2 e = *reinterpret_cast<const float2*>(row + 8);     // x+7, x+8
+                        const float h[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, e.x, e.y};
+                        asm volatile("" ::: "memory");   // one row of values in flight at a time: the gate registers need the room
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {   // dx = 1 - t
+                            const int c27 = n * 3 + t;
+                            if (c27 == 13) continue;
+                            const int k = c27 < 13 ? c27 : c27 - 1;
+                            const int dx = 1 - t;
+                            acc[0] = fmaf(w[k][0].x, h[1 + dx], acc[0]);
+                            acc[1] = fmaf(w[k][0].y, h[2 + dx], acc[1]);
+                            acc[2] = fmaf(w[k][0].z, h[3 + dx], acc[2]);
+                            acc[3] = fmaf(w[k][0].w, h[4 + dx], acc[3]);
+                            acc[4] = fmaf(w[k][1].x, h[5 + dx], acc[4]);
+                            acc[5] = fmaf(w[k][1].y, h[6 + dx], acc[5]);
+                            acc[6] = fmaf(w[k][1].z, h[7 + dx], acc[6]);
+                            acc[7] = fmaf(w[k][1].w, h[8 + dx], acc[7]);
+                        }
+                    }
+                    // voxels outside the volume have zero gates: their value stays 0
+                    const float4 r0 = make_float4(acc[0], acc[1], acc[2], acc[3]), r1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+                    const bool in_zy = z < g.D && y < g.H;
+                    const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
+                    const size_t vox = (size_t)b * V + ((size_t)z * g.H + y) * g.W + x;
+                    if (it == g.n_iter) {
+                        if (in0 && x >= ox0 && x < ox1) *reinterpret_cast<float4*>(out + vox) = r0;
+                        if (in1 && x + 4 >= ox0 && x + 4 < ox1) *reinterpret_cast<float4*>(out + vox + 4) = r1;
+                        break;
+                    }
+                    float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) own[i] = acc[i];
+                    if (in0) st16_sc1(P[it & 1] + vox, r0);
+                    if (in1) st16_sc1(P[it & 1] + vox + 4, r1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const unsigned target = round * 64u + (unsigned)it;
+                    if (tid == 0) __hip_atomic_store(flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nb >= 0) {
+                        unsigned n = 0;
+                        while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                            if (++n > SPIN_MAX) { *err = 2; s_bail = 1; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    __syncthreads();
+                    // ---- the halo shell of the new level, memory-side loads, all of a thread's requests in flight together:
+                    // 36 face rows (two z faces of 10 rows, two y faces of 8) of 64 interior columns as 16-byte loads (576), the
+                    // two end columns of those rows (72) and the two x faces (128) as single words.  Only voxels of neighbour tiles
+                    // inside the window and the volume are read; the rest keeps its initial value.
+                    const float* src = P[it & 1] + (size_t)b * V;
+                    constexpr int NROW = 2 * LY + 2 * TZ, NV4 = NROW * (TX / 4), NEND = 2 * NROW, NXF = 2 * TZ * TY, NITEM = NV4 + NEND + NXF;
+                    constexpr int NSLOT = (NITEM + NTP - 1) / NTP;
+                    v4f hv[NSLOT];
+                    int hl[NSLOT];   // LDS float index, bit 30: a quad; -1: nothing to fetch
+#pragma unroll
+                    for (int j = 0; j < NSLOT; ++j) {
+                        const int item = tid_ + j * NTP;
+                        hl[j] = -1;
+                        hv[j] = v4f{0.f, 0.f, 0.f, 0.f};
+                        if (item >= NITEM) continue;
+                        int pz, py, px, n4 = 0;
+                        if (item < NV4 + NEND) {
+                            const bool v4 = item < NV4;
+                            const int rr = v4 ? item / (TX / 4) : (item - NV4) >> 1;     // face row 0..35
+                            if (rr < 2 * LY) { pz = rr < LY ? 0 : LZ - 1; py = rr < LY ? rr : rr - LY; }
+                            else { const int q = rr - 2 * LY; py = q < TZ ? 0 : LY - 1; pz = 1 + (q < TZ ? q : q - TZ); }
+                            if (v4) { px = 1 + 4 * (item - rr * (TX / 4)); n4 = 1; }
+                            else px = ((item - NV4) & 1) ? LXU - 1 : 0;
+                        } else {
+                            const int q = item - NV4 - NEND, f = q / (TZ * TY), r = q - f * (TZ * TY);
+                            px = f ? LXU - 1 : 0; pz = 1 + r / TY; py = 1 + r - (pz - 1) * TY;
+                        }
+                        const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
+                        const int tz2 = iz + (pz == 0 ? -1 : (pz == LZ - 1 ? 1 : 0)), ty2 = iy + (py == 0 ? -1 : (py == LY - 1 ? 1 : 0)),
+                                  tx2 = ix + (px == 0 ? -1 : (px == LXU - 1 ? 1 : 0));
+                        if (tz2 < 0 || tz2 >= g.tz || ty2 < 0 || ty2 >= g.ty || tx2 < 0 || tx2 >= g.cx) continue;
+                        if (vz < 0 || vz >= g.D || vy < 0 || vy >= g.H || vx < 0 || vx >= g.W) continue;   // (x0 % 4 == 0: a quad is in or out)
+                        const float* gp = src + ((size_t)vz * g.H + vy) * g.W + vx;
+                        hl[j] = ((pz * LY + py) * LX + px) | (n4 << 30);
+                        if (n4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hv[j]) : "v"(gp) : "memory");
+                        else asm volatile("global_load_dword %0, %1, off sc1" : "=v"(hv[j].x) : "v"(gp) : "memory");
+                    }
+#pragma unroll
+                    for (int j = 0; j < NSLOT; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[j]) : : "memory");
+#pragma unroll
+                    for (int j = 0; j < NSLOT; ++j) {
+                        if (hl[j] < 0) continue;
+                        float* lp = nxt + (hl[j] & 0x3fffffff);
+                        lp[0] = hv[j].x;
+                        if (hl[j] >> 30) { lp[1] = hv[j].y; lp[2] = hv[j].z; lp[3] = hv[j].w; }
+                    }
+                    __syncthreads();
+                    if (s_bail) break;
+                }
+            }
+            ++epoch;
+            if (b + 1 < g.B || c + 1 < g.nchunk) grid_barrier(bar, epoch, g.n_wg, err);   // scratch and tiles are reused
+        }
+    }
+}
+
+Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
+    Geo3 g{};
+    g.B = B; g.D = D; g.H = H; g.W = W; g.n_iter = n_iter;
+    g.halo = 4 * ((n_iter + 3) / 4);
+    g.tz = (D + TZ - 1) / TZ;
+    g.ty = (H + TY - 1) / TY;
+    const int per_col = g.tz * g.ty;
+    g.cx = per_col > 0 ? MAX_WG / per_col : 0;
+    const int need = (W + 2 * g.halo + TX - 1) / TX;     // x-tiles that cover a whole row plus halos: no need for more
+    if (g.cx > need) g.cx = need;
+    g.S = g.cx * TX - 2 * g.halo;
+    g.nchunk = g.S > 0 ? (W + g.S - 1) / g.S : 0;
+    g.n_wg = per_col * g.cx;
+    return g;
+}
+
+}  // namespace
+
+bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
+    if (B <= 0 || n_iter < 2 || n_iter > 60 || (W % 4) != 0) return false;
+    const Geo3 g = make_geo3(B, D, H, W, n_iter);
+    // worth it only when a chunk owns clearly more than it recomputes, and the device can hold it
+    return g.cx >= 1 && g.n_wg <= MAX_WG && g.S >= 4 * g.halo && (long long)B * g.nchunk < (1 << 24);
+}
+
+size_t persistent3d_workspace(int B, int D, int H, int W) {
+    return 2 * (size_t)B * D * H * W * sizeof(float) + 4096 * sizeof(unsigned);
+}
+
+int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
+                         hipStream_t st) {
+    const Geo3 g = make_geo3(B, D, H, W, n_iter);
+    const size_t total = (size_t)B * D * H * W;
+    float* scratch = (float*)ws;
+    unsigned* sync = (unsigned*)(scratch + 2 * total);
+    hipError_t e = hipMemsetAsync(sync, 0, 4096 * sizeof(unsigned), st);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(cspn3d_persistent_kernel, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
+    return check_launch("cspn3d_persistent_kernel");
+}
+
+// test hook: the error word of the last run in this workspace (0 ok, 1 barrier timeout, 2 neighbour-flag timeout); syncs
+extern "C" int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) {
+    unsigned v = 0;
+    const unsigned* p = (const unsigned*)((const float*)ws + 2 * (size_t)B * D * H * W) + MAX_WG + 64 * 9;
+    if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
+
+}  // namespace cspn

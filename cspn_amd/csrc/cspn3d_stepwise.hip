@@ -142,14 +142,30 @@ static bool direct3d_ok(const float* g, const float* feat, const float* sparse, 
 
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter) {
     (void)n_iter;
+    return (27 + 2) * (size_t)B * D * H * W * sizeof(float);   // large enough for every mode (fold planes + ping-pong)
+}
+
+// what the chosen path really needs: the Paddle contract (gates used as given, no mask) keeps two value volumes (+ the sync
+// words of the persistent kernel), the folding modes 27 coefficient planes more
+size_t forward3d_workspace(int B, int D, int H, int W, int n_iter, int norm, bool has_sparse) {
+    (void)n_iter;
+    if (norm == CSPN_NORM_NONE && !has_sparse && (W % 4) == 0) return persistent3d_workspace(B, D, H, W);
     return (27 + 2) * (size_t)B * D * H * W * sizeof(float);
 }
 
+// algo: 0 auto, 1 one launch per step, 2 persistent (gates resident across steps)
 int stepwise3d_forward(const float* g, const float* feat, const float* sparse, float* out, int B, int D, int H,
-                       int W, int n_iter, int norm, void* ws, hipStream_t st) {
+                       int W, int n_iter, int norm, void* ws, hipStream_t st, int algo) {
     const size_t total = (size_t)B * D * H * W;
     float* wf = (float*)ws;
-    if (direct3d_ok(g, feat, sparse, out, W, norm, ws)) {
+    const bool direct = direct3d_ok(g, feat, sparse, out, W, norm, ws);
+    if (algo == 2 && !(direct && persistent3d_supported(B, D, H, W, n_iter))) {
+        set_error("persistent 3D kernel does not take this call (needs norm NONE, no mask, W %% 4 == 0, 2 <= n_iter <= 60, a chunk per device)");
+        return CSPN_E_UNSUPPORTED;
+    }
+    if (direct && algo != 1 && persistent3d_supported(B, D, H, W, n_iter))
+        return persistent3d_forward(g, feat, out, B, D, H, W, n_iter, ws, st);
+    if (direct) {
         float* pp[2] = {wf, wf + total};
         const unsigned blocks4 = (unsigned)((total / 4 + 255) / 256);
         const float* src = feat;

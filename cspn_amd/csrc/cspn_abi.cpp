@@ -152,20 +152,34 @@ size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter) {
     return stepwise3d_workspace(B, D, H, W, n_iter);
 }
 
+size_t cspn3d_workspace_bytes_ex(int B, int D, int H, int W, int n_iter, int norm_type, int has_sparse) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    return forward3d_workspace(B, D, H, W, n_iter, norm_type, has_sparse != 0);
+}
+
 int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse, float* out, int B, int D, int H,
                        int W, int n_iter, int norm_type, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    return cspn3d_forward_f32_algo(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, CSPN_ALGO3D_AUTO, ws, ws_bytes, stream);
+}
+
+int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out, int B, int D, int H,
+                            int W, int n_iter, int norm_type, int algo, void* ws, size_t ws_bytes, cspn_stream_t stream) {
     if (B < 0 || D <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d D=%d H=%d W=%d", B, D, H, W); return CSPN_E_BADARG; }
     if (B == 0) return 0;
     if ((long long)B * D * H * W > 0x7fffffffLL / 27) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    size_t need = n_iter == 0 ? 0 : stepwise3d_workspace(B, D, H, W, n_iter);
+    if (algo < CSPN_ALGO3D_AUTO || algo > CSPN_ALGO3D_PERSISTENT) { set_error("unknown 3D algo %d", algo); return CSPN_E_BADARG; }
+    // misaligned tensors cannot take the 16-byte paths: they fold like the normalising modes (cspn3d_workspace_bytes())
+    const bool aligned = ((((uintptr_t)gate | (uintptr_t)feat | (uintptr_t)out | (uintptr_t)ws) & 15u) == 0);
+    size_t need = n_iter == 0 ? 0 : (aligned ? forward3d_workspace(B, D, H, W, n_iter, norm_type, sparse != nullptr)
+                                             : stepwise3d_workspace(B, D, H, W, n_iter));
     if (int e = check_common(gate, feat, out, n_iter, norm_type, ws, ws_bytes, need)) return e;
     if (n_iter == 0) {
         hipError_t e = hipMemcpyAsync(out, feat, sizeof(float) * (size_t)B * D * H * W, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
         return 0;
     }
-    return stepwise3d_forward(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, ws, st);
+    return stepwise3d_forward(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, ws, st, algo);
 }
 
 }  // extern "C"

@@ -152,6 +152,64 @@ int metric_blocks(size_t n) {
     return (int)b;
 }
 
+// ---- sparse-depth sampling on the device (reference createSparseDepthImage: nyu_dataset_loader.py:135-144 keeps each pixel
+// with probability n_sample / n_pixels, kitti_dataset_loader.py:138-148 with n_sample / n_valid, n_valid = #(depth > 1e-4)
+// of that image; sparse = depth * bernoulli(p)).  Counter-based Philox4x32-10: one call yields the four uniforms of four
+// consecutive pixels, keyed by (seed, image), so the mask does not depend on the launch geometry.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1;
+    c[3] = (unsigned)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// per image: number of pixels with depth > 1e-4 (kitti_dataset_loader.py:141), one block per image
+__global__ __launch_bounds__(RB) void count_valid_kernel(const float* __restrict__ depth, size_t hw, float* __restrict__ n_valid) {
+    const float* d = depth + (size_t)blockIdx.x * hw;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < hw; i += RB) acc += d[i] > 0.0001f ? 1.f : 0.f;   // exact below 2^24 pixels per thread
+    acc = wave_sum(acc);
+    __shared__ float part[RB / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < RB / 64; ++i) t += part[i];
+        n_valid[blockIdx.x] = t;
+    }
+}
+
+// n_valid == nullptr: p = n_sample / hw (NYU loader); otherwise p = n_sample / n_valid[image] (KITTI loader)
+__global__ __launch_bounds__(256) void sparse_sample_kernel(const float* __restrict__ depth, float* __restrict__ out, size_t hw,
+                                                             size_t quads_per_image, float n_sample,
+                                                             const float* __restrict__ n_valid, unsigned seed_lo,
+                                                             unsigned seed_hi) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned img = blockIdx.y;
+    if (q >= quads_per_image) return;
+    const float p = n_valid ? n_sample / n_valid[img] : n_sample / (float)hw;   // p >= 1 keeps every pixel
+    unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), img, 0x43535031u};
+    philox4x32_10(c, seed_lo, seed_hi);
+    const size_t base = (size_t)img * hw + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (4 * q + i >= hw) break;
+        const float u = (float)(c[i] >> 8) * (1.0f / 16777216.0f);   // 24 random bits -> [0, 1)
+        out[base + i] = u < p ? depth[base + i] : 0.f;
+    }
+}
+
 }  // namespace
 }  // namespace cspn
 
@@ -203,6 +261,28 @@ int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, in
     hipLaunchKernelGGL(unpool_backward_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
                        grad_x, n_in, W, stride);
     return check_launch("unpool_backward_kernel");
+}
+
+size_t cspn_sparse_sample_workspace_bytes(size_t n_images) { return n_images * sizeof(float); }
+
+// depth, sparse_out: [n_images][hw]; mode 0: keep probability n_sample / hw (reference nyu_dataset_loader.py:135-144),
+// mode 1: n_sample / (number of pixels of that image with depth > 1e-4) (kitti_dataset_loader.py:138-148)
+int cspn_sparse_sample_f32(const float* depth, float* sparse_out, size_t n_images, size_t hw, int n_sample, int mode,
+                           unsigned long long seed, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (!depth || !sparse_out || hw == 0 || n_sample < 0 || (mode != 0 && mode != 1)) { set_error("bad argument"); return CSPN_E_BADARG; }
+    if (n_images == 0) return 0;
+    if (n_images > 65535) { set_error("at most 65535 images per call"); return CSPN_E_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    float* n_valid = nullptr;
+    if (mode == 1) {
+        if (!ws || ws_bytes < cspn_sparse_sample_workspace_bytes(n_images)) { set_error("workspace too small"); return CSPN_E_WORKSPACE; }
+        n_valid = (float*)ws;
+        hipLaunchKernelGGL(count_valid_kernel, dim3((unsigned)n_images), dim3(RB), 0, st, depth, hw, n_valid);
+    }
+    const size_t quads = (hw + 3) / 4;
+    hipLaunchKernelGGL(sparse_sample_kernel, dim3((unsigned)((quads + 255) / 256), (unsigned)n_images), dim3(256), 0, st, depth,
+                       sparse_out, hw, quads, (float)n_sample, n_valid, (unsigned)seed, (unsigned)(seed >> 32));
+    return check_launch("sparse_sample_kernel");
 }
 
 }  // extern "C"

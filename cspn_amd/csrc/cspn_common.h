@@ -30,7 +30,14 @@ int stepwise2d_forward(const float* g, const float* blur, const float* sparse, f
                        int n_iter, int norm, void* ws, hipStream_t st);
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter);
 int stepwise3d_forward(const float* g, const float* feat, const float* sparse, float* out, int B, int D, int H,
-                       int W, int n_iter, int norm, void* ws, hipStream_t st);
+                       int W, int n_iter, int norm, void* ws, hipStream_t st, int algo = 0);
+size_t forward3d_workspace(int B, int D, int H, int W, int n_iter, int norm, bool has_sparse);
+
+// ---- 3D, gates resident in registers for all steps (cspn3d_persistent.hip); Paddle contract only ----
+bool persistent3d_supported(int B, int D, int H, int W, int n_iter);
+size_t persistent3d_workspace(int B, int D, int H, int W);
+int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
+                         hipStream_t st);
 
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);

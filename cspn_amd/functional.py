@@ -131,8 +131,9 @@ def cspn2d_backward_from_history(guidance, blur_depth, sparse_depth, grad_out, h
     return gg, gh
 
 
-def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
-    """gate [B,26,D,H,W], feat [B,1,D,H,W] -> [B,1,D,H,W]; n_iter fused 3x3x3 propagation steps."""
+def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs", algo="auto", _return_ws=False):
+    """gate [B,26,D,H,W], feat [B,1,D,H,W] -> [B,1,D,H,W]; n_iter 3x3x3 propagation steps.  algo: 'auto' | 'stepwise'
+    (one launch per step) | 'persistent' (gates resident in registers across the steps; norm_type 'none' without a mask)."""
     lib = _lib.load()
     if gate.dim() != 5 or gate.shape[1] != 26:
         raise ValueError("gate must be [B,26,D,H,W], got %s" % (tuple(gate.shape),))
@@ -144,14 +145,14 @@ def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
     if B == 0:
         return out
     with torch.cuda.device(g.device):
-        ws_bytes = lib.cspn3d_workspace_bytes(B, D, H, W, int(n_iter))
+        ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type], int(s is not None))
         ws = _workspace(ws_bytes, g.device)
         stream = torch.cuda.current_stream(g.device).cuda_stream
-        rc = lib.cspn3d_forward_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
-                                    out.data_ptr(), B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
-                                    ws.data_ptr(), ws_bytes, stream)
+        rc = lib.cspn3d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                         out.data_ptr(), B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                         _lib.ALGOS_3D[algo], ws.data_ptr(), ws_bytes, stream)
     _lib.check(rc, "cspn3d_forward_f32")
-    return out
+    return (out, ws) if _return_ws else out
 
 
 def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):

@@ -7,6 +7,9 @@
     loss.Wighted_L1_Loss()(pred, label)          loss.py:16-23    Wighted_L1_Loss()(pred, label) -> 0-d tensor, differentiable
     Unpool(num_channels, stride=2)(x)            torch_resnet_cspn_nyu.py:41-54   Unpool(num_channels, stride)(x), differentiable
 
+    createSparseDepthImage(depth_image, n_sample)                 createSparseDepthImage(depth, n_sample, mode='nyu'|'kitti',
+      nyu_dataset_loader.py:135-144, kitti_dataset_loader.py:138-148   seed): the Bernoulli mask drawn on the GPU, batched
+
 The reference moves every prediction to the host before reducing it (train.py:204-206, eval.py:146-150)."""
 import torch
 import torch.nn as nn
@@ -108,3 +111,28 @@ class Unpool(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.num_channels:
             raise ValueError("expected [N,%d,H,W], got %s" % (self.num_channels, tuple(x.shape)))
         return _Unpool.apply(x, self.stride)
+
+
+def createSparseDepthImage(depth_image, n_sample, mode="nyu", seed=0):
+    """reference nyu_dataset_loader.py:135-144 (mode 'nyu': keep probability n_sample / n_pixels) and
+    kitti_dataset_loader.py:138-148 (mode 'kitti': n_sample / n_valid_pixels, valid = depth > 1e-4), on the GPU:
+    sparse_depth = depth_image * bernoulli(p), independently per pixel.  depth_image [..., H, W] on the device (any number
+    of leading dims; every [H, W] slice is one image).  `seed` keys a counter-based generator (a fixed seed reproduces the
+    mask; the reference draws from torch's global CPU generator)."""
+    lib = _lib.load()
+    d = _prep(depth_image, "depth_image")
+    if d.dim() < 2:
+        raise ValueError("depth_image must be [..., H, W]")
+    hw = d.shape[-1] * d.shape[-2]
+    n_images = d.numel() // hw if hw else 0
+    out = torch.empty_like(d)
+    if d.numel() == 0:
+        return out
+    m = {"nyu": 0, "kitti": 1}[mode]
+    with torch.cuda.device(d.device):
+        wsb = lib.cspn_sparse_sample_workspace_bytes(n_images)
+        ws = _workspace(wsb, d.device)
+        rc = lib.cspn_sparse_sample_f32(d.data_ptr(), out.data_ptr(), n_images, hw, int(n_sample), m, int(seed) & (2 ** 64 - 1),
+                                        ws.data_ptr(), wsb, torch.cuda.current_stream(d.device).cuda_stream)
+    _lib.check(rc, "cspn_sparse_sample_f32")
+    return out

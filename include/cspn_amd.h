@@ -104,10 +104,20 @@ int cspn2d_backward_history_f32(const float* guidance, const float* blur, const 
 /* ---- 3D: replaces n_iter chained fluid.layers.affinity_propagate calls,
  * reference cspn_paddle/demo.py:41-43,50-52 (kernel_size == 3 only, demo.py:90)
  *   gate [B,26,D,H,W], feat [B,1,D,H,W], sparse [B,1,D,H,W] or NULL, out [B,1,D,H,W] */
-size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter);
+size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter);   /* enough for every mode */
+/* what this particular call needs with 16-byte aligned tensors (norm NONE without a mask: two value volumes; the folding
+ * modes, and misaligned tensors: 29 = cspn3d_workspace_bytes) */
+size_t cspn3d_workspace_bytes_ex(int B, int D, int H, int W, int n_iter, int norm_type, int has_sparse);
 int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse, float* out,
                        int B, int D, int H, int W, int n_iter, int norm_type,
                        void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+/* algo: AUTO keeps the 26 gates of every voxel in registers across all n_iter steps (persistent kernel, one pass over the
+ * gate tensor per forward) when the call is the Paddle contract (norm NONE, no mask, W % 4 == 0, 16-byte aligned tensors,
+ * 2 <= n_iter <= 60); STEPWISE = one launch and one pass over the gates per step. */
+enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 2 };
+int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
+                            int B, int D, int H, int W, int n_iter, int norm_type, int algo,
+                            void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 /* ---- the steps right next to the path, on the device ----
  * cspn_metrics_f32: reference cspn_pytorch/utils.py:19-47 (evaluate_error) and loss.py:16-23 (Wighted_L1_Loss = MAE
@@ -125,6 +135,15 @@ int cspn_l1_backward_f32(const float* pred, const float* label, const float* sta
                          float* grad_pred, size_t n, cspn_stream_t stream);
 int cspn_unpool_f32(const float* x, float* out, size_t NC, int H, int W, int stride, cspn_stream_t stream);
 int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, int H, int W, int stride, cspn_stream_t stream);
+
+/* cspn_sparse_sample_f32: reference createSparseDepthImage on the device -- sparse = depth * bernoulli(p), p = n_sample /
+ * (pixels per image) for mode 0 (cspn_pytorch/nyu_dataset_loader.py:135-144) or n_sample / (pixels of that image with
+ * depth > 1e-4) for mode 1 (cspn_pytorch/kitti_dataset_loader.py:138-148).  depth, sparse_out: [n_images][hw] floats.
+ * Counter-based generator keyed by (seed, image, pixel): reproducible, independent of launch geometry; NOT the bit stream
+ * of torch.bernoulli.  workspace: cspn_sparse_sample_workspace_bytes(n_images) (only used by mode 1). */
+size_t cspn_sparse_sample_workspace_bytes(size_t n_images);
+int cspn_sparse_sample_f32(const float* depth, float* sparse_out, size_t n_images, size_t hw, int n_sample, int mode,
+                           unsigned long long seed, void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 #ifdef __cplusplus
 }

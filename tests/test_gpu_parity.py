@@ -261,6 +261,29 @@ def test_3d_config5_shape_properties():
     assert rel_err(oc.cpu().numpy(), cspn3d_oracle(gc.cpu(), hc.cpu(), None, 12, "none")) <= RTOL
 
 
+@pytest.mark.parametrize("B,D,H,W,N", [(1, 8, 8, 64, 2),        # one tile, two steps
+                                       (2, 20, 30, 200, 12),    # several tiles in z, y and x; ragged extents; two volumes
+                                       (1, 32, 160, 304, 4),    # config-5 cross-section, two chunks along x (halo recomputation at the cut)
+                                       (1, 32, 160, 152, 3)])   # config-5 cross-section: 80 tile columns, 3 x-tiles per chunk
+def test_3d_persistent_vs_stepwise_and_oracle(B, D, H, W, N):
+    """the persistent kernel (gates resident in registers across the steps, neighbour flags between tiles, chunks with
+    n_iter halo) against the one-launch-per-step kernel on every voxel, and against the 3D oracle where that is quick"""
+    gen = torch.Generator(device=DEV).manual_seed(D * 1000 + H + W)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=DEV)
+    g = g / g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device=DEV)
+    a, ws = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent", _return_ws=True)
+    b = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="stepwise")
+    torch.cuda.synchronize()
+    assert cspn_amd.load().cspn_debug_3d_persistent_error(ws.data_ptr(), B, D, H, W) == 0
+    assert torch.isfinite(a).all()
+    d = (a - b).abs()
+    assert float(d.max()) <= 1e-5 * float(b.abs().max()), float(d.max())
+    assert torch.equal(a, cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent"))   # deterministic
+    if B * D * H * W <= 400000:
+        assert_close(a.cpu().numpy(), cspn3d_oracle(g.cpu(), h.cpu(), None, N, "none"), "3d persistent")
+
+
 def test_paddle_style_affinity_propagate():
     gen = torch.Generator().manual_seed(8)
     x = torch.rand(2, 3, 5, 12, 16, generator=gen)  # C=3 channels share the gates (README.md:56)
