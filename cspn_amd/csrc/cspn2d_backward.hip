@@ -10,6 +10,8 @@
 //           dL/dG_k = dL/dw_k / S - sign(G_k) (sum_j dL/dw_j G_j) / S^2          (torch: d|x|/dx = sign(x), 0 at 0)
 //           dL/dg_k(p + off_k) = dL/dG_k(p)  [* sign(g) for '8sum_abs'];  elements no pixel reads get 0.
 // The H_t history is recomputed here with the stepwise kernels (the fused forward keeps nothing).
+#include <cstdlib>
+
 #include "cspn_common.h"
 
 namespace cspn {
@@ -156,6 +158,200 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
     }
 }
 
+
+// ---- final pass for the assembly sweeps, 4 columns (one register-order group) per thread -------------------------------
+// Same arithmetic as bwd_final_kernel<true>.  Per level a thread reads its group of A (16 bytes) and, for each of the three
+// neighbour rows, its group of H (16 bytes) plus the two single columns beside it: 10 loads for 4 pixels instead of 36, and
+// the 32 dW' products of a level come out of registers.  The epilogue reads / writes the eight guidance planes as 4-column
+// runs (16-byte accesses at 4-byte alignment where the run lies inside the row).
+__device__ __forceinline__ float dpp_shr1(float v) {   // within each row of 16 lanes: lane i <- lane i-1 (first lane: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+}
+__device__ __forceinline__ float dpp_shl1(float v) {   // within each row of 16 lanes: lane i <- lane i+1 (last lane: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));   // row_shl:1
+}
+__device__ __forceinline__ float4 ld4u(const float* p) {   // 16 bytes, 4-byte aligned
+    float4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st4u(float* p, float4 v) { __builtin_memcpy(p, &v, 16); }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
+                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
+                                                          const float* __restrict__ ah, const float* __restrict__ a0p,
+                                                          const float* __restrict__ gout, float* __restrict__ gg,
+                                                          float* __restrict__ gb, int B, int H, int W, int norm) {
+    constexpr int N = 24;
+    const int W4 = W >> 2;
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    // a block = 16 rows x 16 groups (64 columns): a wave holds 4 rows of 16 groups, so the rows above / below a thread's row are
+    // read by the same CU (L1) instead of by another XCD, and the columns beside a group come from the neighbouring lane of
+    // the 16-lane DPP row
+    const int lane = threadIdx.x & 63, gx = lane & 15;
+    const int b = blockIdx.z;
+    const int y = blockIdx.y * 16 + ((threadIdx.x >> 6) << 2) + (lane >> 4);
+    const int xg = blockIdx.x * 16 + gx;
+    const bool valid = y < H && xg < W4;
+    const int x = 4 * (valid ? xg : 0);
+    const size_t base = (size_t)b * HW, idx = base + (size_t)(valid ? y : 0) * W + x;
+    float dW[8][4], dC[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dW[k][i] = 0.f;
+    // one level: A_{t+1} (at ap, image order or register order) times the three rows of H_t around the thread's row
+    auto level = [&](const float* __restrict__ ap, bool a_reg_order, const float* __restrict__ ht, bool h_reg_order) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const float4 q = *reinterpret_cast<const float4*>(ap + idx);
+            if (a_reg_order) { a[0] = q.x; a[1] = q.z; a[2] = q.w; a[3] = q.y; }   // (c0,c3,c1,c2)
+            else { a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dC[i] += a[i];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1: planes 0..2, 3..4, 5..7
+            const int dy = 1 - d, yy = y + dy;
+            const bool rowin = valid && yy >= 0 && yy < H;
+            const float* row = ht + base + (size_t)(rowin ? yy : 0) * W;
+            float h[6];   // columns x-1 .. x+4
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowin) q = *reinterpret_cast<const float4*>(row + x);
+            if (!h_reg_order) { h[1] = q.x; h[2] = q.y; h[3] = q.z; h[4] = q.w; }
+            else { h[1] = q.x; h[2] = q.z; h[3] = q.w; h[4] = q.y; }
+            // the columns beside the group belong to the neighbouring lanes (the next / previous group of the same row); only
+            // the end lanes of a 16-lane row fetch them
+            h[0] = dpp_shr1(h[4]);
+            h[5] = dpp_shl1(h[1]);
+            if (gx == 0 && rowin && x > 0) h[0] = row[h_reg_order ? x - 4 + 1 : x - 1];   // c3 of the group to the left: position 1
+            if (gx == 15 && rowin && x + 4 < W) h[5] = row[x + 4];                          // c0 of the group to the right: position 0
+            if (x == 0) h[0] = 0.f;
+            if (x + 4 >= W) h[5] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (d == 0) {
+                    dW[0][i] = fmaf(a[i], h[i + 2], dW[0][i]);
+                    dW[1][i] = fmaf(a[i], h[i + 1], dW[1][i]);
+                    dW[2][i] = fmaf(a[i], h[i], dW[2][i]);
+                } else if (d == 1) {
+                    dW[3][i] = fmaf(a[i], h[i + 2], dW[3][i]);
+                    dW[4][i] = fmaf(a[i], h[i], dW[4][i]);
+                } else {
+                    dW[5][i] = fmaf(a[i], h[i + 2], dW[5][i]);
+                    dW[6][i] = fmaf(a[i], h[i + 1], dW[6][i]);
+                    dW[7][i] = fmaf(a[i], h[i], dW[7][i]);
+                }
+            }
+        }
+    };
+    // t = 0: H_0 = blur (image order), A_1 = adjoint level N-2;  t = 1..N-2: histories;  t = N-1: A_N = dL/dout
+    level(ah + (size_t)(N - 2) * total, true, blur, false);
+#pragma unroll 2
+    for (int t = 1; t < N - 1; ++t) level(ah + (size_t)(N - 2 - t) * total, true, hh + (size_t)(t - 1) * total, true);
+    level(gout, false, hh + (size_t)(N - 2) * total, true);
+    if (!valid) return;
+    // ---- epilogue: the chain through the fold, the normalisation and the neighbour-sited gather (see the file header)
+    const float4 h0q = *reinterpret_cast<const float4*>(blur + idx);
+    const float h0[4] = {h0q.x, h0q.y, h0q.z, h0q.w};
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sparse) {
+        const float4 sq = *reinterpret_cast<const float4*>(sparse + idx);
+        m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w);
+    }
+    const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
+    const float a0[4] = {a0q.x, a0q.y, a0q.z, a0q.w};
+    const float* gbp = g + (size_t)b * 8 * HW;
+    float* ggp = gg ? gg + (size_t)b * 8 * HW : nullptr;
+    if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
+        if (gb) *reinterpret_cast<float4*>(gb + idx) = make_float4(a0[0] + dC[0] * m[0], a0[1] + dC[1] * m[1], a0[2] + dC[2] * m[2],
+                                                                    a0[3] + dC[3] * m[3]);
+        if (ggp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
+                    make_float4((1.f - m[0]) * dW[k][0], (1.f - m[1]) * dW[k][1], (1.f - m[2]) * dW[k][2], (1.f - m[3]) * dW[k][3]);
+        }
+        return;
+    }
+    // Two passes over the eight planes (the second re-reads its 4-column runs from cache) instead of keeping G, the raw values
+    // and dL/dw of all planes in registers: the kernel has to stay at 4+ waves per SIMD to hide its loads.
+    // G_k(p) = g~_k(p + off_k): a run of four columns of plane k in row y + dy_k starting at x + dx_k, zero outside the image
+    auto run = [&](int k, float (&v)[4]) -> bool {
+        const int yy = y + dy2(k), xs = x + dx2(k);
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (yy < 0 || yy >= H) return false;
+        const float* src = gbp + k * HW + (size_t)yy * W;
+        if (xs >= 0 && xs + 3 < W) {
+            const float4 q = ld4u(src + xs);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xs + i >= 0 && xs + i < W) v[i] = src[xs + i];
+        }
+        return true;
+    };
+    float om[4], ch[4], S[4] = {0.f, 0.f, 0.f, 0.f}, T1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v[4];
+        run(k, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+            S[i] += fabsf(v[i]);
+            gs[i] += G;
+            T1[i] = fmaf(om[i] * (dW[k][i] - ch[i]), G, T1[i]);
+        }
+    }
+    float rS[4], t2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rS[i] = 1.f / S[i]; t2[i] = T1[i] / (S[i] * S[i]); }
+    if (gb) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] / S[i]) + m[i]);
+        *reinterpret_cast<float4*>(gb + idx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (ggp) {
+        // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ys = y - dy2(k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xq = x + i - dx2(k);
+                if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v[4];
+            if (!run(k, v)) continue;  // the zero padding is a constant
+            const int yy = y + dy2(k), xs = x + dx2(k);
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+                const float sg = G > 0.f ? 1.f : (G < 0.f ? -1.f : 0.f);
+                float r = om[i] * (dW[k][i] - ch[i]) * rS[i] - sg * t2[i];
+                if (norm == CSPN_NORM_8SUM_ABS) r *= v[i] > 0.f ? 1.f : (v[i] < 0.f ? -1.f : 0.f);
+                d[i] = r;
+            }
+            float* dst = ggp + k * HW + (size_t)yy * W;   // g_k(p + off_k) is read by pixel p only
+            if (xs >= 0 && xs + 3 < W) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xs + i >= 0 && xs + i < W) dst[xs + i] = d[i];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
@@ -189,8 +385,13 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         const unsigned blocks = (unsigned)((total + 255) / 256);
         if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, st, hh)) return e;
         if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-        hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
-                           H, W, n_iter, norm);
+        static const bool final1 = getenv("CSPN_BWD_FINAL1") != nullptr;   // A/B switch: the one-pixel-per-thread final pass
+        if (final1)
+            hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
+                               H, W, n_iter, norm);
+        else
+            hipLaunchKernelGGL(bwd_final4_kernel, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah,
+                               a0, gout, gg, gb, B, H, W, norm);
         return check_launch("bwd_final_kernel");
     }
     float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
@@ -237,9 +438,9 @@ int backward2d_history(const float* g, const float* blur, const float* sparse, c
     float* ah = (float*)ws;
     float* a0 = ah + 23 * total;
     if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-    hipLaunchKernelGGL(bwd_final_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
-                       gout, gg, gb, B, H, W, 24, norm);
-    return check_launch("bwd_final_kernel");
+    hipLaunchKernelGGL(bwd_final4_kernel, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
+                       gout, gg, gb, B, H, W, norm);
+    return check_launch("bwd_final4_kernel");
 }
 
 }  // namespace cspn
