@@ -11,7 +11,10 @@ Workload (config.workload): BASELINE.json configs[2] -- 2D CSPN 3x3, 24 iteratio
 304x1216 -- at 64 images PER GPU (the full config-3 batch fits one MI355X: 1.0 GB of 288 GB);
 the batch shards embarrassingly, so N>1 is weak scaling with no data-path collective.  The only
 collective is the one-time RCCL broadcast of a backbone-sized weight buffer (outside the timed
-region, reported as broadcast_ms).
+region, reported as broadcast_ms).  Data: image i of the global batch is seeded by 1000 + i on the
+CPU.  Before the counted warm-up the launch runs untimed for --prewarm-s seconds
+(shader clocks settle; reported as prewarm_s); after the timed region the oracle checks a sample
+of `out` (parity_checked).
 """
 import argparse
 import json
@@ -361,8 +364,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("cspn2d_tsw_kernel (gfx950 assembly main loop; one launch per forward + the row-descriptor "
-                           "planning kernel, both inside the timed region)") if algo_name == "fused" and W >= 256 and n_iter == 24
+                "kernel": ("cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup plans its own "
+                           "row stream in LDS, nothing else runs inside the timed region)") if algo_name == "fused" and W >= 256 and n_iter == 24
                           else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
                           else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
                 "achieved": round(achieved, 1),

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                 }
                 // ---- level 0 of the tile and its halo shell into both LDS buffers (outside the volume: 0, for good; outside
                 // the chunk window: the level-0 value, any finite number will do there)
+#pragma unroll 4
                 for (int i = tid; i < LZ * LY * LXU; i += NTP) {
                     const int pz = i / (LY * LXU), r = i - pz * (LY * LXU), py = r / LXU, px = r - py * LXU;
                     const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
