@@ -56,6 +56,9 @@ def parse():
                     help="profiling runs: one torch elementwise kernel over the depth batch before the loop (known byte count, "
                          "calibrates FETCH_SIZE / WRITE_SIZE in the same rocprofv3 trace)")
     ap.add_argument("--no-broadcast", action="store_true")
+    ap.add_argument("--layout", default="planar", choices=["planar", "sited8"],
+                    help="sited8: A/B experiment (DESIGN.md 3.6) -- the guidance is converted ONCE, outside the timed region, to the "
+                         "producer-side [B,H,W/2,8,2] layout and the timed step is cspn2d_forward_sited8_f32")
     return ap.parse_args()
 
 
@@ -280,11 +283,20 @@ def main():
     out = torch.empty_like(h)
     stream = torch.cuda.current_stream(dev)
 
+    g8 = None
+    if a.layout == "sited8":
+        g8 = cspn_amd.guidance_to_sited8(g, a.norm_type)
+        torch.cuda.synchronize()
+
     def step():
-        rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
-                                         out.data_ptr(), B, H, W, n_iter, norm, algo_id, ws.data_ptr(), ws_bytes,
-                                         stream.cuda_stream)
-        _lib.check(rc, "cspn2d_forward_f32_algo")
+        if g8 is not None:
+            rc = lib.cspn2d_forward_sited8_f32(g8.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                               B, H, W, n_iter, norm, stream.cuda_stream)
+        else:
+            rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                             out.data_ptr(), B, H, W, n_iter, norm, algo_id, ws.data_ptr(), ws_bytes,
+                                             stream.cuda_stream)
+        _lib.check(rc, "cspn2d_forward")
 
     if a.pmc_calib:
         _calib = h * 1.0   # reads and writes B*H*W*4 bytes
@@ -359,7 +371,7 @@ def main():
             "config": {
                 "workload": "%s, batch %d per GPU" % (desc, B),
                 "B_per_gpu": B, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
-                "algo": algo_name, "parallelism": "batch-sharded x%d, no data-path collective" % world
+                "algo": algo_name, "guidance_layout": a.layout, "parallelism": "batch-sharded x%d, no data-path collective" % world
                                           + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
             },
             "roofline": {

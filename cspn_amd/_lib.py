@@ -53,6 +53,12 @@ def load():
     lib.cspn2d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp, c_size_t, vp]
     lib.cspn2d_forward_f32_algo.restype = c_int
     lib.cspn2d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    lib.cspn2d_sited8_supported.restype = c_int
+    lib.cspn2d_sited8_supported.argtypes = [c_int] * 4
+    lib.cspn2d_guidance_to_sited8_f32.restype = c_int
+    lib.cspn2d_guidance_to_sited8_f32.argtypes = [vp, vp] + [c_int] * 4 + [vp]
+    lib.cspn2d_forward_sited8_f32.restype = c_int
+    lib.cspn2d_forward_sited8_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp]
     lib.cspn2d_backward_workspace_bytes.restype = c_size_t
     lib.cspn2d_backward_workspace_bytes.argtypes = [c_int] * 4
     lib.cspn2d_backward_f32.restype = c_int

@@ -93,6 +93,28 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
                                    ws_bytes, stream);
 }
 
+// ---- SURVEY 8f-2 experiment: guidance as 32 contiguous bytes per pixel, pre-sited by the producer
+int cspn2d_sited8_supported(int B, int H, int W, int n_iter) { return n_iter == 24 && (W % 2) == 0 && tsw2d_supported(B, H, W) ? 1 : 0; }
+
+int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type, cspn_stream_t stream) {
+    if (!guidance || !guidance_s8 || B <= 0 || H <= 0 || W <= 0 || (W % 2) != 0) { set_error("bad argument (W must be even)"); return CSPN_E_BADARG; }
+    if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
+    if (((uintptr_t)guidance_s8 & 15u) != 0) { set_error("guidance_s8 must be 16-byte aligned"); return CSPN_E_BADARG; }
+    return guidance_to_sited8(guidance, guidance_s8, B, H, W, norm_type, (hipStream_t)stream);
+}
+
+int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const float* sparse, float* out, int B, int H, int W,
+                              int n_iter, int norm_type, cspn_stream_t stream) {
+    if (!guidance_s8 || !blur || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
+    if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
+    if (!cspn2d_sited8_supported(B, H, W, n_iter)) {
+        set_error("the sited8 entry point takes passes of exactly 24 iterations on images >= 256 columns wide, W %% 4 == 0");
+        return CSPN_E_UNSUPPORTED;
+    }
+    if ((((uintptr_t)guidance_s8 | (uintptr_t)out) & 15u) != 0) { set_error("guidance_s8 and out must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
+    return tsw2d_pass_sited8(guidance_s8, blur, sparse, out, B, H, W, norm_type, (hipStream_t)stream);
+}
+
 size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter) {
     if (B <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     return backward2d_workspace(B, H, W, n_iter);

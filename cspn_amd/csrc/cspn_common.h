@@ -49,6 +49,9 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
 bool tsw2d_supported(int B, int H, int W);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
                int W, int norm, hipStream_t st, float* hist = nullptr);
+int guidance_to_sited8(const float* g, float* out, int B, int H, int W, int norm, hipStream_t st);
+int tsw2d_pass_sited8(const float* g8, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm,
+                      hipStream_t st);
 int tsw2d_adjoint_pass(const float* wf, const float* a_in, float* a0, int B, int H, int W, hipStream_t st, float* hist);
 
 // ---- backward of the 2D op (cspn2d_backward.hip) ----

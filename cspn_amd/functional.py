@@ -52,6 +52,37 @@ def cspn2d_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type
     return out
 
 
+def guidance_to_sited8(guidance, norm_type="8sum"):
+    """[B,8,H,W] -> the producer-side layout [B,H,W/2,8,2] of include/cspn_amd.h (SURVEY 8f-2 experiment): what a
+    fused conv epilogue would emit; here a stand-alone kernel."""
+    lib = _lib.load()
+    g = _prep(guidance, "guidance")
+    B, _, H, W = g.shape
+    out = torch.empty(B, H, W // 2, 8, 2, dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib.cspn2d_guidance_to_sited8_f32(g.data_ptr(), out.data_ptr(), B, H, W, _lib.NORM_TYPES[norm_type],
+                                               torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn2d_guidance_to_sited8_f32")
+    return out
+
+
+def cspn2d_forward_sited8(guidance_s8, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum"):
+    """cspn2d_forward with the guidance already in the producer-side layout (24 iterations, W >= 256 only)."""
+    lib = _lib.load()
+    B, H, W2 = guidance_s8.shape[:3]
+    W = 2 * W2
+    g = _prep(guidance_s8, "guidance_s8", (B, H, W2, 8, 2))
+    h = _prep(blur_depth, "blur_depth", (B, 1, H, W))
+    s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
+    out = torch.empty_like(h)
+    with torch.cuda.device(g.device):
+        rc = lib.cspn2d_forward_sited8_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                           B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                           torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn2d_forward_sited8_f32")
+    return out
+
+
 def cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, norm_type="8sum",
                     need_guidance=True, need_blur=True):
     """Gradient of cspn2d_forward w.r.t. guidance and blur_depth (what autograd computes through reference

@@ -73,6 +73,19 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
 /* which kernel AUTO would run for this shape: CSPN_ALGO_STEPWISE or CSPN_ALGO_FUSED */
 int cspn2d_auto_algo(int B, int H, int W, int n_iter);
 
+/* ---- 2D with the guidance in a producer-side layout (an ADDITIONAL entry point, the contract above is
+ * unchanged).  guidance_s8 = [B][H][W/2][8][2] floats: the record of the pixel pair (x, x+1), x even, holds
+ * (G_0(x), G_0(x+1), G_1(x), ..., G_7(x+1)) with G_k(p) = g_k(p + off_k), zero outside the image -- the gather of
+ * reference cspn.py:91-132 done by whoever writes the guidance (its natural home is the epilogue of the conv at
+ * cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206,372); norm NONE: the centre-sited g_k(p).
+ * cspn2d_guidance_to_sited8_f32 is that epilogue as a stand-alone kernel (tests, A/B timing).  Only where
+ * cspn2d_sited8_supported(...) != 0 (passes of exactly 24 iterations, W >= 256, W % 4 == 0); no workspace. */
+int cspn2d_sited8_supported(int B, int H, int W, int n_iter);
+int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type,
+                                  cspn_stream_t stream);
+int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const float* sparse, float* out,
+                              int B, int H, int W, int n_iter, int norm_type, cspn_stream_t stream);
+
 /* ---- 2D backward: the gradient torch autograd computes through Affinity_Propagate.forward (reference cspn.py:42-83),
  * i.e. what reference cspn_pytorch/train.py:196-198 back-propagates through.
  *   grad_out      [B,1,H,W]  dL/d(out)

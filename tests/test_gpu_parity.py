@@ -328,6 +328,34 @@ def test_asm_loop_parity_vs_oracle(B, H, W, N, norm, sp):
         assert_close_tight(o, ref, a)
 
 
+@pytest.mark.parametrize("B,H,W,norm,sp", [(2, 40, 256, "8sum", True), (1, 70, 516, "8sum_abs", False), (3, 33, 304, "none", True),
+                                           (4, 304, 1216, "8sum", True)])
+def test_sited8_entry_point_vs_oracle(B, H, W, norm, sp):
+    """SURVEY 8f-2 experiment: the additional entry point that takes the guidance in the producer-side layout
+    ([B,H,W/2,8,2], gathered by cspn2d_guidance_to_sited8_f32) against the oracle on the ORIGINAL tensors, and bit for bit
+    against the planar entry point (same loop, same arithmetic, only the loads differ)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.tswgen.run_emu import sited8
+    g, h, s = make_inputs(B, H, W, seed=3 * B + H + W, sparse=sp, neg=sp, depth_scale=80.0)
+    if norm == "none":
+        g = g.abs() / (g.abs().sum(1, keepdim=True) + 0.25)
+    elif H > 20:
+        g[0, :, 9:12, 100:108] = 0.0
+    gd = g.to(DEV)
+    g8 = cspn_amd.guidance_to_sited8(gd, norm)
+    assert np.array_equal(g8.cpu().numpy(), sited8(g.numpy(), {"8sum": 0, "8sum_abs": 1, "none": 2}[norm]))   # the layout kernel
+    out = cspn_amd.cspn2d_forward_sited8(g8, h.to(DEV), None if s is None else s.to(DEV), 24, norm)
+    planar = cspn_amd.cspn2d_forward(gd, h.to(DEV), None if s is None else s.to(DEV), 24, norm, "fused")
+    torch.cuda.synchronize()
+    nz = ~torch.isnan(planar)
+    assert torch.equal(torch.isnan(out), torch.isnan(planar)) and torch.equal(out[nz], planar[nz])
+    if B * H * W <= 200000:
+        assert_close_tight(out.cpu().numpy(), cspn2d_oracle(g, h, s, 24, norm), "sited8")
+    with pytest.raises(cspn_amd.CspnError):
+        cspn_amd.cspn2d_forward_sited8(g8, h.to(DEV), None, 12, norm)   # only whole 24-iteration passes
+
+
 def test_asm_plan_table_matches_python_planner():
     """the descriptor tables the workgroups build for themselves (same device functions, dumped by a test hook) ==
     tools/tswgen/plan.py (which the CPU emulator tests run on)"""

@@ -32,6 +32,14 @@ def test_emulated_asm_loop_vs_oracle(B, H, W, n_wg, norm, sparse, hin, zp):
         assert np.isnan(ref).any()
 
 
+@pytest.mark.parametrize("norm,sparse", [(0, True), (1, False), (2, True)])
+def test_emulated_sited8_input_variant(norm, sparse):
+    """cfg s8 (SURVEY 8f-2 experiment): the guidance arrives pre-sited and pair-interleaved, four aligned 16-byte loads per task"""
+    os.chdir(ROOT)
+    err, nanmis, _, ref = run_case(2, 15, 304, 4, norm, sparse, False, seed=11, zero_patch=(norm != 2), verbose=False, s8=True)
+    assert nanmis == 0 and err <= 1e-4
+
+
 def test_emulated_history_variant_writes_every_level():
     """cfg hist (used by the backward pass): levels 1..23 of every owned pixel, checked against the oracle level by level"""
     os.chdir(ROOT)

@@ -102,7 +102,14 @@ class Gen(object):
         self.adj = cfg.get("adj", False)
         if self.adj:
             assert self.norm == 2 and not self.sparse and not self.hin
-        self.sited = self.norm != 2 or self.adj   # guidance plane k is read at (y + dy_k, x + dx_k)
+        # s8: the guidance comes "pre-sited, pair-interleaved" -- [B][H][W/2][8][2] floats, record of pixel pair (x, x+1) =
+        # (G_0(x), G_0(x+1), G_1(x), ...) with G_k(p) = g_k(p + off_k) already gathered (zero outside the image) by the producer
+        # (cspn2d_guidance_to_sited8_f32): a task's guidance is four aligned 16-byte loads instead of eight unaligned 8-byte ones
+        # and needs no edge patching (SURVEY 8f-2 experiment)
+        self.s8 = cfg.get("s8", False)
+        if self.s8:
+            assert not self.adj and not self.hist
+        self.sited = (self.norm != 2 or self.adj) and not self.s8   # guidance plane k is read at (y + dy_k, x + dx_k)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
@@ -401,18 +408,16 @@ class Gen(object):
             loads = self.load_list()
             if self.cfg.get("spread3", False):   # a third of the requests now, the rest in the two following steps
                 loads = loads[0::3]
-            for i, (dst, voff, base) in enumerate(loads):
-                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
-                       at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
+            for i, item in enumerate(loads):
+                self.emit_load(item, at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / len(loads))
             if self.cfg.get("pf", False):
                 self.issue_prefetch(at=0.95)
         elif self.cfg.get("spread3", False) and "nocook" not in self.ab:
             # the pending task's remaining requests: the scalar row bases (s2:3, s6:11) and the lane offsets are still in
             # place; the data is consumed at the next step with counter % 3 == 2
             part = self.load_list()[(c % 3) + 1::3]
-            for i, (dst, voff, base) in enumerate(part):
-                self.e("global_load_dwordx2", dst, [voff, base], cache=self.cfg.get("ld_cache"),
-                       at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / max(1, len(part)))
+            for i, item in enumerate(part):
+                self.emit_load(item, at=self.cfg.get("load_at", 0.1) + self.cfg.get("load_span", 0.7) * i / max(1, len(part)))
         # received boundary rows
         self.shift(BQ, D_BQ)
         self.push_below(3, BQ, D_BQ, N1[3])
@@ -616,6 +621,11 @@ class Gen(object):
             self.e("s_add_i32", T[6], [S_W4, 16])
             self.e("s_sub_u32", GB_MID[0], [GB_MID[0], T[6]])
             self.e("s_subb_u32", GB_MID[1], [GB_MID[1], 0])
+        elif self.s8:   # 32 bytes per pixel: the row starts at 8 x its 1-channel byte offset
+            self.e("s_lshr_b32", T[7], [cd[2], 29])
+            self.e("s_lshl_b32", T[6], [cd[2], 3])
+            self.e("s_add_u32", GB_MID[0], [S_GD[0], T[6]])
+            self.e("s_addc_u32", GB_MID[1], [S_GD[1], T[7]])
         else:
             self.e("s_add_u32", GB_MID[0], [S_GD[0], cd[0]])
             self.e("s_addc_u32", GB_MID[1], [S_GD[1], cd[1]])
@@ -629,26 +639,36 @@ class Gen(object):
             self.e("s_addc_u32", B_SP[1], [S_SP[1], 0])
 
     def load_list(self):
+        """-> [(op, dst, lane-offset register, scalar base, immediate offset)] of the pending task"""
         if "nocookload" in self.ab:
             return []
-        bases = [GB_MID] * 8
-        items = [(PEND_G[k], V_OFFK[k], bases[k]) for k in range(8)]
-        if "alignedloads" in self.ab:
-            items = [(PEND_G[k], V_OFF1, bases[k]) for k in range(8)]
-        if "halfloads" in self.ab:
-            items = items[:4]
-        if "sameload" in self.ab:
-            items = [(PEND_G[k], V_OFFK[k], S_GD) for k in range(8)]
-        items.append((PEND_BLUR, V_OFF1, B_BLUR))
+        X2, X4 = "global_load_dwordx2", "global_load_dwordx4"
+        if self.s8:
+            items = [(X4, V(PEND_G[0].i + 4 * i, 4), V_OFFK[0], GB_MID, 16 * i) for i in range(4)]
+        else:
+            items = [(X2, PEND_G[k], V_OFFK[k], GB_MID, 0) for k in range(8)]
+            if "alignedloads" in self.ab:
+                items = [(X2, PEND_G[k], V_OFF1, GB_MID, 0) for k in range(8)]
+            if "halfloads" in self.ab:
+                items = items[:4]
+            if "sameload" in self.ab:
+                items = [(X2, PEND_G[k], V_OFFK[k], S_GD, 0) for k in range(8)]
+        items.append((X2, PEND_BLUR, V_OFF1, B_BLUR, 0))
         if self.hin:
-            items.append((PEND_HIN, V_OFF1, B_HIN))
+            items.append((X2, PEND_HIN, V_OFF1, B_HIN, 0))
         if self.sparse:
-            items.append((PEND_SP, V_OFF1, B_SP))
+            items.append((X2, PEND_SP, V_OFF1, B_SP, 0))
         return items
 
+    def emit_load(self, item, **m):
+        op, dst, voff, base, off = item
+        if off:
+            m["offset"] = off
+        self.e(op, dst, [voff, base], cache=self.cfg.get("ld_cache"), **m)
+
     def issue_loads(self, items):
-        for dst, voff, base in items:
-            self.e("global_load_dwordx2", dst, [voff, base])
+        for it in items:
+            self.emit_load(it)
 
     def issue_prefetch(self, **m):
         """cfg pf: the task after the one just requested (descriptor in S_CD) reads rows 4 further down the stream: touch its
@@ -754,7 +774,11 @@ class Gen(object):
         e("v_lshlrev_b32", V_OFF1, [3, V_LANE])
         e("s_lshl_b32", T[3], [T[1], 9])
         e("v_add_u32", V_OFF1, [T[3], V_OFF1])
-        for k in range(8):
+        if self.s8:   # the lane's pixel pair inside a row of 64-byte pair records: 64 * (64 * (wv&1) + lane)
+            e("v_lshlrev_b32", V_OFFK[0], [6, V_LANE])
+            e("s_lshl_b32", T[3], [T[1], 12])
+            e("v_add_u32", V_OFFK[0], [T[3], V_OFFK[0]])
+        for k in ([] if self.s8 else range(8)):
             e("s_mul_i32", T[3], [S_HW4, (7 - k) if self.adj else k])   # S_HW4: bytes from one guidance plane to the next
             if self.sited:
                 if DY[k] > 0:

@@ -10,7 +10,8 @@ from .emu import Emu, EmuError
 from .plan import build_plan
 
 
-def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False):
+def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False,
+             s8=False):
     sys.path.insert(0, ".")
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
@@ -29,7 +30,8 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     hinv = None
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
-    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist), sched=sched)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, s8=s8), sched=sched)
+    g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
     nb = len(plan_bands(W, n_iter))
@@ -39,7 +41,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     def al(n):
         return (n + 4095) // 4096 * 4096
     off, cur = {}, 8192
-    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("out", np.zeros_like(blur)), ("plan", tab), ("hist", histbuf)):
+    for name, arr in (("gd", g_dev), ("blur", blur), ("hin", hinv), ("sp", sp), ("out", np.zeros_like(blur)), ("plan", tab), ("hist", histbuf)):
         if arr is None:
             off[name] = 4096
             continue
@@ -47,7 +49,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         cur += al(arr.nbytes) + 4096 + (8192 if name == "plan" else 0)
     mem = np.zeros(cur + 4096, np.uint8)
     mem.view(np.float32)[:] = np.nan
-    for name, arr in (("gd", g), ("blur", blur), ("hin", hinv), ("sp", sp), ("plan", tab)):
+    for name, arr in (("gd", g_dev), ("blur", blur), ("hin", hinv), ("sp", sp), ("plan", tab)):
         if arr is not None:
             mem[off[name]:off[name] + arr.nbytes] = arr.view(np.uint8).ravel()
     t0 = time.time()
@@ -118,6 +120,24 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         print("   per wave-step: VALU %.1f SALU %.1f nop %.1f mem %.1f (steps %d)" % (
             nv / 8 / steps / n_wg, ns / 8 / steps / n_wg, nn / 8 / steps / n_wg, nm / 8 / steps / n_wg, steps))
     return err, nanmis.sum(), out, ref
+
+
+def sited8(g, norm):
+    """the pre-sited, pair-interleaved guidance layout of cfg s8: [B][H][W/2][8][2], element (k, e) of pair xp = G_k(2 xp + e) with
+    G_k(p) = g_k(p + off_k) (zero outside the image) for the normalising modes, g_k(p) for norm 'none'
+    (numpy twin of cspn2d_guidance_to_sited8_f32)"""
+    B, _, H, W = g.shape
+    out = np.zeros((B, H, W // 2, 8, 2), np.float32)
+    for k in range(8):
+        if norm == 2:
+            G = g[:, k]
+        else:
+            pad = np.zeros((B, H + 2, W + 2), np.float32)
+            pad[:, 1:-1, 1:-1] = g[:, k]
+            G = pad[:, 1 + K.DY[k]:1 + K.DY[k] + H, 1 + K.DX[k]:1 + K.DX[k] + W]
+        out[:, :, :, k, 0] = G[:, :, 0::2]
+        out[:, :, :, k, 1] = G[:, :, 1::2]
+    return out
 
 
 def fill_table(emu, tab_wg):
