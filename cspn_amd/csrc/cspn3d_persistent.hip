@@ -240,6 +240,18 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
     }
 }
 
+// workgroups that can be resident at once: one per CU (the kernel takes a CU's whole register file), at most MAX_WG.  The
+// per-tile flags only work if every tile of a chunk is running.
+int resident_wgs() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return MAX_WG;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return MAX_WG;
+        return v < MAX_WG ? v : MAX_WG;
+    }();
+    return n;
+}
+
 Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
     Geo3 g{};
     g.B = B; g.D = D; g.H = H; g.W = W; g.n_iter = n_iter;
@@ -247,7 +259,7 @@ Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
     g.tz = (D + TZ - 1) / TZ;
     g.ty = (H + TY - 1) / TY;
     const int per_col = g.tz * g.ty;
-    g.cx = per_col > 0 ? MAX_WG / per_col : 0;
+    g.cx = per_col > 0 ? resident_wgs() / per_col : 0;
     const int need = (W + 2 * g.halo + TX - 1) / TX;     // x-tiles that cover a whole row plus halos: no need for more
     if (g.cx > need) g.cx = need;
     g.S = g.cx * TX - 2 * g.halo;
@@ -262,7 +274,7 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || n_iter < 2 || n_iter > 60 || (W % 4) != 0) return false;
     const Geo3 g = make_geo3(B, D, H, W, n_iter);
     // worth it only when a chunk owns clearly more than it recomputes, and the device can hold it
-    return g.cx >= 1 && g.n_wg <= MAX_WG && g.S >= 4 * g.halo && (long long)B * g.nchunk < (1 << 24);
+    return g.cx >= 1 && g.n_wg <= resident_wgs() && g.S >= 4 * g.halo && (long long)B * g.nchunk < (1 << 24);
 }
 
 size_t persistent3d_workspace(int B, int D, int H, int W) {
