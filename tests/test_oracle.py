@@ -1,4 +1,6 @@
 """CPU: the oracle (oracle/cspn_oracle.c) against the reference's own outputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -6,6 +8,8 @@ import torch
 from helpers import RTOL, make_inputs, rel_err
 from oracle import cspn2d_oracle, cspn3d_oracle
 from oracle import ref_harness
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NORMS = {0: "8sum", 1: "8sum_abs"}
 
@@ -77,3 +81,19 @@ def test_oracle3d_constant_fixed_point_and_none_mode():
     gn = g / g.sum(1, keepdim=True)
     out = cspn3d_oracle(gn, const, None, 1, "none")
     assert np.abs(out[0, 0, 1:-1, 1:-1, 1:-1] - 2.0).max() < 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cspn_pytorch"), reason="the reference tree only exists in the build container")
+def test_aux_golden_is_what_the_reference_files_produce(tmp_path, monkeypatch):
+    """tests/golden/aux_golden.npz (metrics + loss vectors for the device mirrors) regenerates bit for bit from the unmodified
+    reference utils.py / loss.py through the committed recipe"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_aux_golden", os.path.join(ROOT, "tests", "golden", "make_aux_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "OUT", str(tmp_path / "aux.npz"))
+    mod.main()
+    a, b = np.load(str(tmp_path / "aux.npz")), np.load(os.path.join(ROOT, "tests", "golden", "aux_golden.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

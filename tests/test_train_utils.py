@@ -122,3 +122,31 @@ def test_sparse_depth_sampling_on_device_matches_loader_statistics():
     # odd sizes (hw % 4 != 0) and a single image without channel dim
     s = tu.createSparseDepthImage(torch.ones(7, 9, device="cuda"), 63)
     assert s.shape == (7, 9) and float(s.sum()) == 63.0      # p = 1: keeps everything
+
+
+def _aux_golden():
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_golden.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    return {n: {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")} for n in names}
+
+
+def test_metrics_and_loss_vs_vectors_of_the_reference_files():
+    """tests/golden/aux_golden.npz was produced by the UNMODIFIED reference cspn_pytorch/utils.py (evaluate_error) and loss.py
+    (Wighted_L1_Loss + its autograd gradient) via tests/golden/make_aux_golden.py: the device mirrors must reproduce them"""
+    import numpy as np
+    import cspn_amd.train_utils as tu
+    keys = ['MSE', 'RMSE', 'ABS_REL', 'LG10', 'MAE', 'DELTA1.02', 'DELTA1.05', 'DELTA1.10', 'DELTA1.25', 'DELTA1.25^2', 'DELTA1.25^3']
+    for name, c in _aux_golden().items():
+        gt, pred = torch.from_numpy(c["gt"]).to(DEV), torch.from_numpy(c["pred"]).to(DEV)
+        err = tu.evaluate_error(gt, pred)
+        for i, k in enumerate(keys):
+            ref = float(c["metrics"][i])
+            assert abs(err[k] - ref) <= 2e-5 * max(abs(ref), 1e-3), (name, k, err[k], ref)
+        if "loss" in c:
+            p = pred.clone().requires_grad_(True)
+            loss = tu.Wighted_L1_Loss()(p, gt)
+            loss.backward()
+            assert abs(float(loss) - float(c["loss"][0])) <= 1e-5 * float(c["loss"][0]), name
+            assert np.allclose(p.grad.cpu().numpy(), c["grad_pred"], rtol=1e-5, atol=1e-9), name
