@@ -70,6 +70,12 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
     unsigned* flags = sync;                  // [MAX_WG] per-tile step flags
     unsigned* bar = sync + MAX_WG;           // [64 * 9] barrier counters (one cache line each)
     unsigned* err = sync + MAX_WG + 64 * 9;  // [1]
+#ifdef P3_TRACE
+    unsigned long long* trc = reinterpret_cast<unsigned long long*>(sync + 2048);   // [n_iter][6] stamps of workgroup 37, chunk 1
+#define P3_STAMP(k) if (wg == 37 && tid == 0 && round == 1) trc[(it - 1) * 6 + (k)] = __builtin_readcyclecounter()
+#else
+#define P3_STAMP(k)
+#endif
     const int tid = threadIdx.x, wg = blockIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
     float* P[2] = {scratch, scratch + total};
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     const int lx = (tid_ & 7) * 8, ly = (tid_ >> 3) & 7, lz = tid_ >> 6;
                     const float* cur = lds + ((it - 1) & 1) * LTILE;
                     float* nxt = lds + (it & 1) * LTILE;
+                    P3_STAMP(0);
                     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int n = 0; n < 9; ++n) {   // the 9 neighbour rows (dz, dy); three x-taps each
@@ -170,10 +177,12 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
+                    P3_STAMP(1);
                     if (in0) st16_sc1(P[it & 1] + vox, r0);
                     if (in1) st16_sc1(P[it & 1] + vox + 4, r1);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
+                    P3_STAMP(2);
                     const unsigned target = round * 64u + (unsigned)it;
                     if (tid == 0) __hip_atomic_store(flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (nb >= 0) {
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                         }
                     }
                     __syncthreads();
+                    P3_STAMP(3);
                     // ---- the halo shell of the new level, memory-side loads, all of a thread's requests in flight together:
                     // 36 face rows (two z faces of 10 rows, two y faces of 8) of 64 interior columns as 16-byte loads (576), the
                     // two end columns of those rows (72) and the two x faces (128) as single words.  Only voxels of neighbour tiles
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                         if (hl[j] >> 30) { lp[1] = hv[j].y; lp[2] = hv[j].z; lp[3] = hv[j].w; }
                     }
                     __syncthreads();
+                    P3_STAMP(4);
                     if (s_bail) break;
                 }
             }

@@ -1,0 +1,17 @@
+"""per-step phases of the persistent 3D kernel (build with -DP3_TRACE): cycles of workgroup 37 in chunk 1"""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cspn_amd
+B, D, H, W, N = 4, 32, 160, 608, 12
+g = torch.rand(B, 26, D, H, W, device="cuda"); g /= g.sum(1, keepdim=True)
+h = torch.rand(B, 1, D, H, W, device="cuda")
+for _ in range(3):
+    o, ws = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent", _return_ws=True)
+torch.cuda.synchronize()
+sync = ws[2 * B * D * H * W * 4:].view(torch.int32)
+t = sync[2048:2048 + N * 12].cpu().numpy().view(np.uint64).reshape(N, 6).astype(np.int64)
+names = ["compute", "stores+wait+sync", "flag+poll+sync", "halo loads+sync"]
+d = np.diff(t[:N - 1, :5], axis=1)
+print("mean cycles per phase (100 MHz? counter: s_memrealtime / readcyclecounter units):")
+for n, v in zip(names, d.mean(0)): print("  %-20s %10.1f" % (n, v))
+print("  step to step        %10.1f" % np.diff(t[:N - 1, 0]).mean())
