@@ -347,6 +347,12 @@ class Gen(object):
         cook = (c % 3 == 2 or (stag and c % 3 == 0)) and "nocook" not in self.ab
         cook_hi = stag and c % 3 == 0          # this variant cooks the tasks of waves 4..7
         g = (((c + 1) // 3) if c % 3 == 2 else (c // 3)) & 1
+        # cook_early: the pending task is normalised and written to the ring at the END of the step before (counter % 3 == 1),
+        # behind the chain, where every wave but the one with an event has slack before the barrier; the step with
+        # counter % 3 == 2 then only requests the next task
+        early = self.cfg.get("cook_early", False) and "nocook" not in self.ab
+        cook_math_here = cook and not early
+        cook_at_end = early and c % 3 == 1
 
         def guard():
             """-> label to jump to for the waves that do not cook in this variant"""
@@ -357,6 +363,10 @@ class Gen(object):
             self.e("s_cbranch_scc0" if cook_hi else "s_cbranch_scc1", (), [lab])
             return lab
         self.p.label(".LS%d_%%=" % c)
+        # an event makes this wave the slowest of the step while the wave it shares its SIMD with has slack: let it issue first
+        prio = self.cfg.get("prio", 1) if ev is not None else 0
+        if prio:
+            self.e("raw", (), ["s_setprio %d" % prio])
         self.probe(0)
         assert not stag, "the stagger option was dropped (measured 1 % slower)"
         partial = self.cfg.get("partial_wait", True) and not self.cfg.get("trace", False)
@@ -383,7 +393,7 @@ class Gen(object):
             if "noevlds" in self.ab:
                 n_after = 2
         loads, deferred = [], []
-        if cook:
+        if cook_math_here:
             # normalise + fold the pending task while the boundary rows arrive (c' and H0 go to the ring at once, the eight
             # coefficient planes from the main region below)
             deferred = self.cook_pending(V_RINGW[g])
@@ -453,7 +463,11 @@ class Gen(object):
                 self.push_self(j, vq, tq, N2[j], late=late)
             if j < 3:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8), late=late)
+        if cook_at_end:
+            self.ring_writes(self.cook_pending(V_RINGW[((c + 2) // 3) & 1]))
         self.probe(3)
+        if prio:
+            self.e("raw", (), ["s_setprio 0"])
         self.p.waitcnt(lgkm=0)
         self.probe(4)
         if "nobar" not in self.ab:
