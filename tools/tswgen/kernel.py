@@ -245,11 +245,12 @@ class Gen(object):
         self.e("s_mov_b64", EXEC, [-1])
         self.p.label(lab)
 
-    def inject(self, j, vq):
+    def inject(self, j, vq, hn=HN, copy=True):
         for k in self.late_planes(j):
             self.ring_read(WT(j, k), V_RINGE[0], k, at=0.0)
-        for i in (1, 0, 2, 3):   # the DPP sources first
-            self.mov(vq[i], HN[i])
+        if copy:   # slots 1..3 use the freshly read quad itself as the row's level-0 value (nothing reads vq before it is
+            for i in (1, 0, 2, 3):   # re-initialised); slot 0's deferred tail needs it in the accumulator register
+                self.mov(vq[i], hn[i])
         self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
         self.e("s_bitcmp1_b32", (), [S_ENF, F_ACTIVE])
         self.e("s_cselect_b32", T[2], [1 << j, 0])
@@ -370,6 +371,11 @@ class Gen(object):
         self.probe(0)
         assert not stag, "the stagger option was dropped (measured 1 % slower)"
         partial = self.cfg.get("partial_wait", True) and not self.cfg.get("trace", False)
+        # slim events: the H0 quad read for the row entering slot ev is, one step later, the "row above" of the row entering
+        # slot ev + 1 (a wave's four events are consecutive steps): two quads alternate, nothing is read twice; and slots
+        # 1..3 use the quad as the row's level-0 value directly
+        slim = self.cfg.get("slim_events", True)
+        hn, ha = (HN, HA) if (not slim or ev is None or ev % 2 == 0) else (HA, HN)
         # ---- top: everything that travels through LDS is requested first; what the chain needs at once comes first, because
         # the LDS operations of a wave complete in order and the waits below count the requests that may stay outstanding
         if "nolds" not in self.ab:
@@ -382,14 +388,16 @@ class Gen(object):
             self.fetch_event(ev)
             n_after += 2
             self.e("v_add_u32", V_RINGE[0], [ev * RING_SLOT, V_RINGR])
-            self.ring_read(HN, V_RINGE[0], 9, at=0.0)
+            self.ring_read(hn, V_RINGE[0], 9, at=0.0)
             n_after += 2
             if ev > 0:
-                self.e("v_add_u32", V_RINGE[1], [(ev - 1) * RING_SLOT, V_RINGR])
-                self.ring_read(HA, V_RINGE[1], 9, at=0.0)
+                if not slim:
+                    self.e("v_add_u32", V_RINGE[1], [(ev - 1) * RING_SLOT, V_RINGR])
+                    self.ring_read(ha, V_RINGE[1], 9, at=0.0)
+                    n_after += 2
                 for k in self.early_planes(ev):
                     self.ring_read(WT(ev, k), V_RINGE[0], k, at=0.0)
-                n_after += 2 + 2 * len(self.early_planes(ev))
+                n_after += 2 * len(self.early_planes(ev))
             if "noevlds" in self.ab:
                 n_after = 2
         loads, deferred = [], []
@@ -442,7 +450,9 @@ class Gen(object):
                     self.p.waitcnt(lgkm=0)
                     self.take_event()
                 self.retire(j, vq)
-                self.inject(j, vq)
+                self.inject(j, vq, hn, copy=not (slim and j > 0))
+                if slim and j > 0:
+                    vq = hn
             elif "noact" not in self.ab:
                 self.act_check(j, vq)
             if self.hist and ev != j:
@@ -457,8 +467,8 @@ class Gen(object):
             self.push_below(j - 1, vq, tq, N1[j - 1])
             if ev == j:
                 self.push_self(j, vq, tq, N2[j], init=WT(j, 8), late=late)
-                self.shift(HA, D_BQ)
-                self.push_above(j, HA, D_BQ, N2[j], late=late)
+                self.shift(ha, D_BQ)
+                self.push_above(j, ha, D_BQ, N2[j], late=late)
             else:
                 self.push_self(j, vq, tq, N2[j], late=late)
             if j < 3:
@@ -709,6 +719,9 @@ class Gen(object):
         # state
         for r in range(ACC_BASE, WT_BASE + 144):
             self.mov(V(r), 0)
+        for i in range(4):   # wave 7 enters the loop at its slot-3 event: the "row above" quad of that first event
+            self.mov(HN[i], 0)
+            self.mov(HA[i], 0)
         for k in range(8):
             self.mov(PEND_G[k][0], 0)
             self.mov(PEND_G[k][1], 0)
