@@ -686,6 +686,10 @@ class Gen(object):
 
     def emit_load(self, item, **m):
         op, dst, voff, base, off = item
+        if self.cfg.get("ld32", False) and op == "global_load_dwordx2":   # experiment: two 4-byte loads instead of one 8-byte load
+            for i in (0, 1):
+                self.e("global_load_dword", dst[i], [voff, base], cache=self.cfg.get("ld_cache"), offset=off + 4 * i, **m)
+            return
         if off:
             m["offset"] = off
         self.e(op, dst, [voff, base], cache=self.cfg.get("ld_cache"), **m)
