@@ -15,6 +15,8 @@
 //
 // Only the Paddle contract (norm NONE, no sparse mask, W % 4 == 0, 16-byte aligned tensors); other modes run
 // cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
+#include <cstdlib>
+
 #include "cspn_common.h"
 
 namespace cspn {
@@ -62,6 +64,23 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned epoch, int 
     __syncthreads();
 }
 
+// published boundary of a tile, TAGGED exchange: 28 face rows (z faces: lz in {0,7} x ly 0..7; y faces: ly in {0,7} x lz 1..6) of
+// 22 quads each (three consecutive x per quad + the step tag; quad 21 holds x = 63) and the 72 x-face voxels (lx in {0,63},
+// lz, ly 1..6) three per quad: NQ quads of 16 bytes per tile and level parity
+constexpr int QROW = 22, NFROW = 28, NQ = NFROW * QROW + 24;   // 640
+
+__device__ __forceinline__ int face_row_of(int lz, int ly) {   // row index of a boundary row (lz in {0,7} or ly in {0,7})
+    if (lz == 0 || lz == TZ - 1) return (lz == 0 ? 0 : 1) * TY + ly;
+    return 2 * TY + (ly == 0 ? 0 : 1) * (TZ - 2) + (lz - 1);
+}
+
+__device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) {   // uniform base + per-lane 32-bit offset
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+    return v;
+}
+
+template <bool TAGGED>
 __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
                                                                  float* __restrict__ out, float* __restrict__ scratch,
                                                                  unsigned* __restrict__ sync, Geo3 g) {
@@ -79,6 +98,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
     const int tid = threadIdx.x, wg = blockIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
     float* P[2] = {scratch, scratch + total};
+    float4* X = reinterpret_cast<float4*>(scratch + 2 * total);   // TAGGED: [2][n_wg][NQ] published boundaries
     const int tiles = g.tz * g.ty * g.cx;
     const bool have_tile = wg < tiles;
     const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
@@ -178,12 +198,128 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
                     P3_STAMP(1);
+                    const unsigned target = round * 64u + (unsigned)it;
+                    if (TAGGED) {
+                        // ---- publish the tile's boundary as self-validating 16-byte quads (three values + the step tag): no
+                        // wait for the stores, no flag -- a reader polls the quad it needs until the tag is the step's
+                        __syncthreads();   // the new level is complete in LDS
+                        float4* mine = X + ((size_t)(it & 1) * g.n_wg + wg) * NQ;
+#pragma unroll
+                        for (int j = 0; j < (NQ + NTP - 1) / NTP; ++j) {
+                            const int t = tid_ + j * NTP;
+                            if (t >= NQ) continue;
+                            float v3[3] = {0.f, 0.f, 0.f};
+                            if (t < NFROW * QROW) {
+                                const int r = t / QROW, q = t - r * QROW;
+                                int rz, ry;
+                                if (r < 2 * TY) { rz = r < TY ? 0 : TZ - 1; ry = r < TY ? r : r - TY; }
+                                else { const int u = r - 2 * TY; ry = u < TZ - 2 ? 0 : TY - 1; rz = 1 + (u < TZ - 2 ? u : u - (TZ - 2)); }
+                                const float* rowp = nxt + ((rz + 1) * LY + (ry + 1)) * LX + 1 + 3 * q;
+#pragma unroll
+                                for (int e = 0; e < 3; ++e)
+                                    if (3 * q + e < TX) v3[e] = rowp[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 3; ++e) {
+                                    const int v = (t - NFROW * QROW) * 3 + e;
+                                    if (v < 2 * (TZ - 2) * (TY - 2)) {
+                                        const int f = v / ((TZ - 2) * (TY - 2)), u = v - f * ((TZ - 2) * (TY - 2));
+                                        const int rz = 1 + u / (TY - 2), ry = 1 + u - (rz - 1) * (TY - 2);
+                                        v3[e] = nxt[((rz + 1) * LY + (ry + 1)) * LX + 1 + (f ? TX - 1 : 0)];
+                                    }
+                                }
+                            }
+                            st16_sc1(reinterpret_cast<float*>(mine + t), make_float4(v3[0], v3[1], v3[2], __uint_as_float(target)));
+                        }
+                        P3_STAMP(2);
+                        P3_STAMP(3);
+                        // ---- the halo shell: 36 face rows of the neighbours above / below (22 quads each) and the 200 voxels beside
+                        // the tile (from the x neighbours), polled until their tag is this step's
+                        constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL;
+                        constexpr int NSLOT = (NIT + NTP - 1) / NTP;
+                        unsigned src[NSLOT];   // byte offset of the quad in X
+                        int dstp[NSLOT];   // LDS float index | element << 24 | (3 values) << 28 ; -1: nothing to fetch
+#pragma unroll
+                        for (int j = 0; j < NSLOT; ++j) {
+                            const int item = tid_ + j * NTP;
+                            dstp[j] = -1;
+                            src[j] = 0;
+                            if (item >= NIT) continue;
+                            int pz, py, px, quad, elem = 0, three = 0;
+                            if (item < NHQ) {
+                                const int hr = item / QROW;
+                                quad = item - hr * QROW;
+                                if (hr < 2 * LY) { pz = hr < LY ? 0 : LZ - 1; py = hr < LY ? hr : hr - LY; }
+                                else { const int u = hr - 2 * LY; py = u < TZ ? 0 : LY - 1; pz = 1 + (u < TZ ? u : u - TZ); }
+                                px = 1 + 3 * quad;
+                                three = 1;
+                            } else {
+                                const int u = item - NHQ, f = u / (LZ * LY), r = u - f * (LZ * LY);
+                                pz = r / LY; py = r - pz * LY; px = f ? LXU - 1 : 0;
+                                quad = 0;
+                            }
+                            const int tz2 = iz + (pz == 0 ? -1 : (pz == LZ - 1 ? 1 : 0)), ty2 = iy + (py == 0 ? -1 : (py == LY - 1 ? 1 : 0)),
+                                      tx2 = ix + (px == 0 ? -1 : (px == LXU - 1 ? 1 : 0));
+                            if (tz2 < 0 || tz2 >= g.tz || ty2 < 0 || ty2 >= g.ty || tx2 < 0 || tx2 >= g.cx) continue;
+                            if (tz2 == iz && ty2 == iy && tx2 == ix) continue;   // (cannot happen: every item lies outside the tile)
+                            // the voxel inside the neighbour tile
+                            const int sz = pz == 0 ? TZ - 1 : (pz == LZ - 1 ? 0 : pz - 1), sy = py == 0 ? TY - 1 : (py == LY - 1 ? 0 : py - 1);
+                            if (!three) {
+                                const int sx = px == 0 ? TX - 1 : 0;
+                                if (sz == 0 || sz == TZ - 1 || sy == 0 || sy == TY - 1) {
+                                    quad = face_row_of(sz, sy) * QROW + (sx == 0 ? 0 : QROW - 1);
+                                    elem = 0;
+                                } else {
+                                    const int v = (sx == 0 ? 0 : 1) * ((TZ - 2) * (TY - 2)) + (sz - 1) * (TY - 2) + (sy - 1);
+                                    quad = NFROW * QROW + v / 3;
+                                    elem = v - (v / 3) * 3;
+                                }
+                            } else {
+                                quad = face_row_of(sz, sy) * QROW + quad;
+                            }
+                            const int nbw = (tz2 * g.ty + ty2) * g.cx + tx2;
+                            src[j] = (unsigned)((((it & 1) * g.n_wg + nbw) * NQ + quad) * 16);
+                            dstp[j] = ((pz * LY + py) * LX + px) | (elem << 24) | (three << 28);
+                        }
+                        unsigned tries = 0;
+                        bool pend = false;
+#pragma unroll
+                        for (int j = 0; j < NSLOT; ++j) pend = pend || dstp[j] >= 0;
+                        while (pend) {
+                            v4f qv[NSLOT];
+#pragma unroll
+                            for (int j = 0; j < NSLOT; ++j)
+                                if (dstp[j] >= 0) qv[j] = ldq_sc1(X, src[j]);
+#pragma unroll
+                            for (int j = 0; j < NSLOT; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qv[j]) : : "memory");
+                            pend = false;
+#pragma unroll
+                            for (int j = 0; j < NSLOT; ++j) {
+                                if (dstp[j] < 0) continue;
+                                if (__float_as_uint(qv[j].w) == target) {
+                                    float* lp = nxt + (dstp[j] & 0xffffff);
+                                    if (dstp[j] >> 28) {
+                                        const int x0 = (dstp[j] & 0xffffff) % LX;   // px of the first value: values beyond the tile's 64 columns are padding
+                                        lp[0] = qv[j].x;
+                                        if (x0 + 1 <= TX) lp[1] = qv[j].y;
+                                        if (x0 + 2 <= TX) lp[2] = qv[j].z;
+                                    } else {
+                                        const int e = (dstp[j] >> 24) & 3;
+                                        lp[0] = e == 0 ? qv[j].x : (e == 1 ? qv[j].y : qv[j].z);
+                                    }
+                                    dstp[j] = -1;
+                                } else {
+                                    pend = true;
+                                }
+                            }
+                            if (pend && ++tries > SPIN_MAX) { *err = 2; s_bail = 1; break; }
+                        }
+                    } else {
                     if (in0) st16_sc1(P[it & 1] + vox, r0);
                     if (in1) st16_sc1(P[it & 1] + vox + 4, r1);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     P3_STAMP(2);
-                    const unsigned target = round * 64u + (unsigned)it;
                     if (tid == 0) __hip_atomic_store(flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (nb >= 0) {
                         unsigned n = 0;
@@ -240,6 +376,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                         lp[0] = hv[j].x;
                         if (hl[j] >> 30) { lp[1] = hv[j].y; lp[2] = hv[j].z; lp[3] = hv[j].w; }
                     }
+                    }
                     __syncthreads();
                     P3_STAMP(4);
                     if (s_bail) break;
@@ -288,8 +425,10 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
     return g.cx >= 1 && g.n_wg <= resident_wgs() && g.S >= 4 * g.halo && (long long)B * g.nchunk < (1 << 24);
 }
 
+constexpr size_t XBYTES = 2 * (size_t)MAX_WG * NQ * 16;   // published tile boundaries, two level parities
+
 size_t persistent3d_workspace(int B, int D, int H, int W) {
-    return 2 * (size_t)B * D * H * W * sizeof(float) + 4096 * sizeof(unsigned);
+    return 2 * (size_t)B * D * H * W * sizeof(float) + XBYTES + 4096 * sizeof(unsigned);
 }
 
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
@@ -297,17 +436,22 @@ int persistent3d_forward(const float* gate, const float* feat, float* out, int B
     const Geo3 g = make_geo3(B, D, H, W, n_iter);
     const size_t total = (size_t)B * D * H * W;
     float* scratch = (float*)ws;
-    unsigned* sync = (unsigned*)(scratch + 2 * total);
-    hipError_t e = hipMemsetAsync(sync, 0, 4096 * sizeof(unsigned), st);
+    unsigned* sync = (unsigned*)((char*)(scratch + 2 * total) + XBYTES);
+    static const bool flags_mode = getenv("CSPN_3D_FLAGS") != nullptr;   // A/B switch: the flag-based exchange of the first version
+    // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
+    hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(cspn3d_persistent_kernel, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
+    if (flags_mode)
+        hipLaunchKernelGGL(cspn3d_persistent_kernel<false>, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
+    else
+        hipLaunchKernelGGL(cspn3d_persistent_kernel<true>, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
     return check_launch("cspn3d_persistent_kernel");
 }
 
 // test hook: the error word of the last run in this workspace (0 ok, 1 barrier timeout, 2 neighbour-flag timeout); syncs
 extern "C" int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) {
     unsigned v = 0;
-    const unsigned* p = (const unsigned*)((const float*)ws + 2 * (size_t)B * D * H * W) + MAX_WG + 64 * 9;
+    const unsigned* p = (const unsigned*)((const char*)((const float*)ws + 2 * (size_t)B * D * H * W) + XBYTES) + MAX_WG + 64 * 9;
     if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)v;
 }
