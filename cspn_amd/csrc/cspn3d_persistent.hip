@@ -76,7 +76,7 @@ __device__ __forceinline__ int face_row_of(int lz, int ly) {   // row index of a
 
 __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) {   // uniform base + per-lane 32-bit offset
     v4f v;
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
     return v;
 }
 
@@ -92,8 +92,10 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
 #ifdef P3_TRACE
     unsigned long long* trc = reinterpret_cast<unsigned long long*>(sync + 2048);   // [n_iter][6] stamps of workgroup 37, chunk 1
 #define P3_STAMP(k) if (wg == 37 && tid == 0 && round == 1) trc[(it - 1) * 6 + (k)] = __builtin_readcyclecounter()
+#define P3_CHUNK(k) if (wg == 37 && tid == 0 && round == 1) trc[g.n_iter * 6 + (k)] = __builtin_readcyclecounter()
 #else
 #define P3_STAMP(k)
+#define P3_CHUNK(k)
 #endif
     const int tid = threadIdx.x, wg = blockIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
@@ -102,7 +104,6 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
     const int tiles = g.tz * g.ty * g.cx;
     const bool have_tile = wg < tiles;
     const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
-    const int lx = (tid & 7) * 8, ly = (tid >> 3) & 7, lz = tid >> 6;   // 8 consecutive x per thread
     if (tid == 0) s_bail = 0;
     // neighbour tile of this thread (threads 0..25), -1: none inside the chunk window
     int nb = -1;
@@ -119,35 +120,98 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                 const int ox0 = c * g.S, ox1 = min(g.W, ox0 + g.S);     // owned columns of the chunk
                 const int wx0 = ox0 - g.halo;                            // window start (may be negative)
                 const int z0 = iz * TZ, y0 = iy * TY, x0 = wx0 + ix * TX;
+                P3_CHUNK(0);
+                // ---- level 0 first (its loads are issued ahead of the gates' so that they return first): the thread's own eight
+                // voxels and its share of the 2504-voxel halo shell (outside the volume: 0, for good; outside the chunk window:
+                // the level-0 value, any finite number will do there).
+                // All of these loads are issued by hand (uniform base + 32-bit lane offset, lanes outside the volume clamped to offset
+                // 0 and zeroed afterwards) so that the count in flight is known: 2 + NSHT level-0 loads, then 52 gate loads
+                // (59 <= the 63 vmcnt can count), level 0 goes to LDS while the gates are still arriving, and nothing is spilled
+                // in between (a spill reload would queue behind every load in flight).  The s_nop in front of each load covers the
+                // "VALU wrote the SGPR base (v_readlane of a spilled SGPR) -> VMEM reads it" hazard, which the compiler cannot see
+                // inside inline assembly.
+                constexpr int SH_Z = 2 * LY * LXU, SH_Y = 2 * TZ * LXU, SH_X = 2 * TZ * TY, NSH = SH_Z + SH_Y + SH_X;
+                constexpr int NSHT = (NSH + NTP - 1) / NTP;
+                int tc = tid;   // opaque per chunk: nothing below may be hoisted out of the chunk loop (it would be spilled, and a
+                asm volatile("" : "+v"(tc));   // spill reload waits for every load in flight)
+                const int lx = (tc & 7) * 8, ly = (tc >> 3) & 7, lz = tc >> 6;
+                const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+                const bool in_zy = z < g.D && y < g.H;
+                const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
+                const unsigned voff = (unsigned)((z * g.H + y) * g.W + x) * 4u;
+                const unsigned voff0 = in0 ? voff : 0u, voff1 = in1 ? voff + 16u : 0u;
+                auto shell_pos = [&](int i, int& pz, int& py, int& px) {
+                    if (i < SH_Z) { pz = i < LY * LXU ? 0 : LZ - 1; const int r = i < LY * LXU ? i : i - LY * LXU; py = r / LXU; px = r - py * LXU; }
+                    else if (i < SH_Z + SH_Y) { const int u = i - SH_Z, r = u / LXU; px = u - r * LXU; pz = 1 + (r >> 1); py = (r & 1) ? LY - 1 : 0; }
+                    else { const int u = i - SH_Z - SH_Y, r = u >> 1; px = (u & 1) ? LXU - 1 : 0; pz = 1 + r / TY; py = 1 + r % TY; }
+                };
+                v4f f0, f1;
+                float fs[NSHT];
+                const float* fb = feat + (size_t)b * V;
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f0) : "v"(voff0), "s"(fb) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f1) : "v"(voff1), "s"(fb) : "memory");
+#pragma unroll
+                for (int j = 0; j < NSHT; ++j) {
+                    const int i = tc + j * NTP;
+                    int pz, py, px;
+                    shell_pos(i, pz, py, px);
+                    const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
+                    const bool ok = i < NSH && vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
+                    const unsigned so = ok ? (unsigned)((vz * g.H + vy) * g.W + vx) * 4u : 0u;
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(fs[j]) : "v"(so), "s"(fb) : "memory");
+                }
                 // ---- the 26 gates of the thread's eight voxels: read once, kept in registers for all steps
-                float4 w[26][2];
-                {
+                v4f w[26][2];
+#pragma unroll
+                for (int k = 0; k < 26; ++k) {
+                    const float* gk = gate + ((size_t)b * 26 + k) * V;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
+                }
+                {   // level 0 into both LDS buffers once ITS loads are back (52 gate loads may still be in flight)
+                    asm volatile("s_waitcnt vmcnt(52)" : "+v"(f0), "+v"(f1) : : "memory");
+#pragma unroll
+                    for (int j = 0; j < NSHT; ++j) asm volatile("" : "+v"(fs[j]));
+                    int tid_ = tid;
+                    asm volatile("" : "+v"(tid_));
+                    const int lx = (tid_ & 7) * 8, ly = (tid_ >> 3) & 7, lz = tid_ >> 6;
                     const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
                     const bool in_zy = z < g.D && y < g.H;
                     const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
-                    const float* gb = gate + (size_t)b * 26 * V + ((size_t)z * g.H + y) * g.W + x;
+                    const int o = ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
+                    const float own8[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
-                    for (int k = 0; k < 26; ++k) {
-                        v4f t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-                        if (in0) t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gb + (size_t)k * V));
-                        if (in1) t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gb + (size_t)k * V + 4));
-                        w[k][0] = make_float4(t0.x, t0.y, t0.z, t0.w);
-                        w[k][1] = make_float4(t1.x, t1.y, t1.z, t1.w);
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = (i < 4 ? in0 : in1) ? own8[i] : 0.f;
+                        lds[o + i] = v;
+                        lds[LTILE + o + i] = v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NSHT; ++j) {
+                        const int i = tid_ + j * NTP;
+                        int pz, py, px;
+                        shell_pos(i, pz, py, px);
+                        const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
+                        const bool ok = vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
+                        if (i < NSH) {
+                            const float v = ok ? fs[j] : 0.f;
+                            lds[(pz * LY + py) * LX + px] = v;
+                            lds[LTILE + (pz * LY + py) * LX + px] = v;
+                        }
                     }
                 }
-                // ---- level 0 of the tile and its halo shell into both LDS buffers (outside the volume: 0, for good; outside
-                // the chunk window: the level-0 value, any finite number will do there)
-#pragma unroll 4
-                for (int i = tid; i < LZ * LY * LXU; i += NTP) {
-                    const int pz = i / (LY * LXU), r = i - pz * (LY * LXU), py = r / LXU, px = r - py * LXU;
-                    const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
-                    float v = 0.f;
-                    if (vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W)
-                        v = feat[(size_t)b * V + ((size_t)vz * g.H + vy) * g.W + vx];
-                    lds[(pz * LY + py) * LX + px] = v;
-                    lds[LTILE + (pz * LY + py) * LX + px] = v;
+                // the gates are back; outside the volume they are zero (such voxels keep the value 0)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]) : : "memory");
+#pragma unroll
+                for (int k = 0; k < 26; ++k) {
+                    if (k) asm volatile("" : "+v"(w[k][0]), "+v"(w[k][1]));
+                    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+                    w[k][0] = in0 ? w[k][0] : zero;
+                    w[k][1] = in1 ? w[k][1] : zero;
                 }
+                P3_CHUNK(1);
                 __syncthreads();
+                P3_CHUNK(2);
                 for (int it = 1; it <= g.n_iter; ++it) {
                     // the 208 gate registers leave no room for loop-invariant addresses: everything below is recomputed from
                     // tid_ each step (a handful of integer instructions) instead of being kept live across the loop
@@ -198,12 +262,14 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
                     P3_STAMP(1);
-                    const unsigned target = round * 64u + (unsigned)it;
+                    // TAGGED: publications are numbered through the whole launch and alternate between the two buffers, so the
+                    // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
+                    const unsigned target = TAGGED ? round * (unsigned)(g.n_iter - 1) + (unsigned)it : round * 64u + (unsigned)it;
                     if (TAGGED) {
                         // ---- publish the tile's boundary as self-validating 16-byte quads (three values + the step tag): no
                         // wait for the stores, no flag -- a reader polls the quad it needs until the tag is the step's
                         __syncthreads();   // the new level is complete in LDS
-                        float4* mine = X + ((size_t)(it & 1) * g.n_wg + wg) * NQ;
+                        float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
 #pragma unroll
                         for (int j = 0; j < (NQ + NTP - 1) / NTP; ++j) {
                             const int t = tid_ + j * NTP;
@@ -278,7 +344,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                                 quad = face_row_of(sz, sy) * QROW + quad;
                             }
                             const int nbw = (tz2 * g.ty + ty2) * g.cx + tx2;
-                            src[j] = (unsigned)((((it & 1) * g.n_wg + nbw) * NQ + quad) * 16);
+                            src[j] = (unsigned)((((int)(target & 1) * g.n_wg + nbw) * NQ + quad) * 16);
                             dstp[j] = ((pz * LY + py) * LX + px) | (elem << 24) | (three << 28);
                         }
                         unsigned tries = 0;
@@ -379,11 +445,15 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     }
                     __syncthreads();
                     P3_STAMP(4);
-                    if (s_bail) break;
+                    if (s_bail) {
+                        if (TAGGED) return;   // a neighbour never published (error word set): nothing below can complete
+                        break;
+                    }
                 }
+                P3_CHUNK(3);
             }
             ++epoch;
-            if (b + 1 < g.B || c + 1 < g.nchunk) grid_barrier(bar, epoch, g.n_wg, err);   // scratch and tiles are reused
+            if (!TAGGED && (b + 1 < g.B || c + 1 < g.nchunk)) grid_barrier(bar, epoch, g.n_wg, err);   // scratch and tiles are reused
         }
     }
 }

@@ -8,8 +8,11 @@ h = torch.rand(B, 1, D, H, W, device="cuda")
 for _ in range(3):
     o, ws = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent", _return_ws=True)
 torch.cuda.synchronize()
-sync = ws[2 * B * D * H * W * 4:].view(torch.int32)
-t = sync[2048:2048 + N * 12].cpu().numpy().view(np.uint64).reshape(N, 6).astype(np.int64)
+sync = ws[2 * B * D * H * W * 4 + 2 * 256 * 640 * 16:].view(torch.int32)
+raw = sync[2048:2048 + (N + 1) * 12].cpu().numpy().view(np.uint64).astype(np.int64)
+t = raw[:N * 6].reshape(N, 6)
+ck = raw[N * 6:N * 6 + 4]
+print("chunk: gate loads %d, level-0 fill %d, %d steps %d cycles" % (ck[1] - ck[0], ck[2] - ck[1], N, ck[3] - ck[2]))
 names = ["compute", "stores+wait+sync", "flag+poll+sync", "halo loads+sync"]
 d = np.diff(t[:N - 1, :5], axis=1)
 print("mean cycles per phase (100 MHz? counter: s_memrealtime / readcyclecounter units):")
