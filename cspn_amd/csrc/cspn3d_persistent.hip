@@ -64,15 +64,13 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned epoch, int 
     __syncthreads();
 }
 
-// published boundary of a tile, TAGGED exchange: 28 face rows (z faces: lz in {0,7} x ly 0..7; y faces: ly in {0,7} x lz 1..6) of
-// 22 quads each (three consecutive x per quad + the step tag; quad 21 holds x = 63) and the 72 x-face voxels (lx in {0,63},
-// lz, ly 1..6) three per quad: NQ quads of 16 bytes per tile and level parity
-constexpr int QROW = 22, NFROW = 28, NQ = NFROW * QROW + 24;   // 640
-
-__device__ __forceinline__ int face_row_of(int lz, int ly) {   // row index of a boundary row (lz in {0,7} or ly in {0,7})
-    if (lz == 0 || lz == TZ - 1) return (lz == 0 ? 0 : 1) * TY + ly;
-    return 2 * TY + (ly == 0 ? 0 : 1) * (TZ - 2) + (lz - 1);
-}
+// published boundary of a tile, TAGGED exchange, in 16-byte quads = up to three values + the step tag in the fourth word.  Thread xg
+// of row (lz, ly) owns the quads q3 = 0, 1, 2 of its values (0,1,2) (3,4,5) (6,7), stored at [q3][row][xg] so that a wave's store (and
+// a reader's load) covers whole 128-byte lines; written for boundary rows only.  The x faces (value 0 of xg = 0, value 7 of xg = 7)
+// of ALL rows follow at [side][row], one value per quad.
+constexpr int QROW = 24, NROWS = TZ * TY, NQA = NROWS * QROW, NQ = NQA + 2 * NROWS;   // 1536 + 128 quads per tile and level parity
+// what a tile fetches per step: 36 halo rows (above / below / beside in y) of 24 quads, and the 200 voxels beside it in x
+constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL, NSLOT = (NIT + NTP - 1) / NTP;
 
 __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) {   // uniform base + per-lane 32-bit offset
     v4f v;
@@ -165,8 +163,19 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
                     const float* gk = gate + ((size_t)b * 26 + k) * V;
+#if defined(P3_EXP_NT)   // timing experiments (profiles/r02_perf_notes.md): the nontemporal hint costs 10 % of the forward
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
+#elif defined(P3_EXP_LANE_REMAP)   // WRONG RESULTS: each instruction reads 128 contiguous bytes per row
+                    const int xa = x0 + (tc & 7) * 4;
+                    const unsigned ra = (unsigned)((z * g.H + y) * g.W + xa) * 4u;
+                    const unsigned r0_ = (in_zy && xa >= 0 && xa + 3 < g.W) ? ra : 0u, r1_ = (in_zy && xa + 32 >= 0 && xa + 35 < g.W) ? ra + 128u : 0u;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(r0_), "s"(gk) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(r1_), "s"(gk) : "memory");
+#else
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
+#endif
                 }
                 {   // level 0 into both LDS buffers once ITS loads are back (52 gate loads may still be in flight)
                     asm volatile("s_waitcnt vmcnt(52)" : "+v"(f0), "+v"(f1) : : "memory");
@@ -266,91 +275,68 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
                     const unsigned target = TAGGED ? round * (unsigned)(g.n_iter - 1) + (unsigned)it : round * 64u + (unsigned)it;
                     if (TAGGED) {
-                        // ---- publish the tile's boundary as self-validating 16-byte quads (three values + the step tag): no
-                        // wait for the stores, no flag -- a reader polls the quad it needs until the tag is the step's
-                        __syncthreads();   // the new level is complete in LDS
-                        float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
-#pragma unroll
-                        for (int j = 0; j < (NQ + NTP - 1) / NTP; ++j) {
-                            const int t = tid_ + j * NTP;
-                            if (t >= NQ) continue;
-                            float v3[3] = {0.f, 0.f, 0.f};
-                            if (t < NFROW * QROW) {
-                                const int r = t / QROW, q = t - r * QROW;
-                                int rz, ry;
-                                if (r < 2 * TY) { rz = r < TY ? 0 : TZ - 1; ry = r < TY ? r : r - TY; }
-                                else { const int u = r - 2 * TY; ry = u < TZ - 2 ? 0 : TY - 1; rz = 1 + (u < TZ - 2 ? u : u - (TZ - 2)); }
-                                const float* rowp = nxt + ((rz + 1) * LY + (ry + 1)) * LX + 1 + 3 * q;
-#pragma unroll
-                                for (int e = 0; e < 3; ++e)
-                                    if (3 * q + e < TX) v3[e] = rowp[e];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 3; ++e) {
-                                    const int v = (t - NFROW * QROW) * 3 + e;
-                                    if (v < 2 * (TZ - 2) * (TY - 2)) {
-                                        const int f = v / ((TZ - 2) * (TY - 2)), u = v - f * ((TZ - 2) * (TY - 2));
-                                        const int rz = 1 + u / (TY - 2), ry = 1 + u - (rz - 1) * (TY - 2);
-                                        v3[e] = nxt[((rz + 1) * LY + (ry + 1)) * LX + 1 + (f ? TX - 1 : 0)];
-                                    }
-                                }
+                        // ---- publish the tile's boundary straight from the registers as self-validating 16-byte quads (up to three
+                        // values + the step tag): no wait for the stores, no flag, no barrier -- a reader polls the quad it needs
+                        // until the tag is the step's.  A thread's eight values are the quads (0,1,2) (3,4,5) (6,7) of its row;
+                        // boundary rows publish all 24, the others only the first and the last (the x faces).
+                        {
+                            float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
+                            float4* rowq = mine + (lz * TY + ly) * 8 + (lx >> 3);
+                            const float tagf = __uint_as_float(target);
+                            if (lz == 0 || lz == TZ - 1 || ly == 0 || ly == TY - 1) {
+                                st16_sc1(reinterpret_cast<float*>(rowq), make_float4(acc[0], acc[1], acc[2], tagf));
+                                st16_sc1(reinterpret_cast<float*>(rowq + NROWS * 8), make_float4(acc[3], acc[4], acc[5], tagf));
+                                st16_sc1(reinterpret_cast<float*>(rowq + 2 * NROWS * 8), make_float4(acc[6], acc[7], 0.f, tagf));
                             }
-                            st16_sc1(reinterpret_cast<float*>(mine + t), make_float4(v3[0], v3[1], v3[2], __uint_as_float(target)));
+                            if (lx == 0) st16_sc1(reinterpret_cast<float*>(mine + NQA + lz * TY + ly), make_float4(acc[0], 0.f, 0.f, tagf));
+                            if (lx == TX - 8) st16_sc1(reinterpret_cast<float*>(mine + NQA + NROWS + lz * TY + ly), make_float4(acc[7], 0.f, 0.f, tagf));
                         }
-                        P3_STAMP(2);
-                        P3_STAMP(3);
-                        // ---- the halo shell: 36 face rows of the neighbours above / below (22 quads each) and the 200 voxels beside
-                        // the tile (from the x neighbours), polled until their tag is this step's
-                        constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL;
-                        constexpr int NSLOT = (NIT + NTP - 1) / NTP;
+                        // ---- the halo shell: 36 rows of the neighbours above / below / beside in y (24 quads each) and the 200 voxels
+                        // beside the tile in x (one value of a neighbour's first or last quad), polled until their tag is this step's
                         unsigned src[NSLOT];   // byte offset of the quad in X
-                        int dstp[NSLOT];   // LDS float index | element << 24 | (3 values) << 28 ; -1: nothing to fetch
+                        int dstp[NSLOT];       // LDS float index | count << 14 ; -1: nothing to fetch
 #pragma unroll
                         for (int j = 0; j < NSLOT; ++j) {
+                            // (recomputed every step: a table of these in LDS was measured no faster, and the registers to keep
+                            // them are taken by the gates)
                             const int item = tid_ + j * NTP;
                             dstp[j] = -1;
                             src[j] = 0;
                             if (item >= NIT) continue;
-                            int pz, py, px, quad, elem = 0, three = 0;
+                            int pz, py, px, q3 = -1, xg = 0, cnt = 1;
                             if (item < NHQ) {
-                                const int hr = item / QROW;
-                                quad = item - hr * QROW;
+                                const int hr = item / QROW, quad = item - hr * QROW;
                                 if (hr < 2 * LY) { pz = hr < LY ? 0 : LZ - 1; py = hr < LY ? hr : hr - LY; }
                                 else { const int u = hr - 2 * LY; py = u < TZ ? 0 : LY - 1; pz = 1 + (u < TZ ? u : u - TZ); }
-                                px = 1 + 3 * quad;
-                                three = 1;
+                                q3 = quad >> 3;
+                                xg = quad & 7;
+                                px = 1 + 8 * xg + 3 * q3;
+                                cnt = q3 == 2 ? 2 : 3;
                             } else {
                                 const int u = item - NHQ, f = u / (LZ * LY), r = u - f * (LZ * LY);
                                 pz = r / LY; py = r - pz * LY; px = f ? LXU - 1 : 0;
-                                quad = 0;
+                                xg = f ? 0 : 1;      // right halo: the neighbour's x = 0 (side 0); left halo: its x = 63 (side 1)
                             }
                             const int tz2 = iz + (pz == 0 ? -1 : (pz == LZ - 1 ? 1 : 0)), ty2 = iy + (py == 0 ? -1 : (py == LY - 1 ? 1 : 0)),
                                       tx2 = ix + (px == 0 ? -1 : (px == LXU - 1 ? 1 : 0));
                             if (tz2 < 0 || tz2 >= g.tz || ty2 < 0 || ty2 >= g.ty || tx2 < 0 || tx2 >= g.cx) continue;
-                            if (tz2 == iz && ty2 == iy && tx2 == ix) continue;   // (cannot happen: every item lies outside the tile)
-                            // the voxel inside the neighbour tile
+                            // the row inside the neighbour tile
                             const int sz = pz == 0 ? TZ - 1 : (pz == LZ - 1 ? 0 : pz - 1), sy = py == 0 ? TY - 1 : (py == LY - 1 ? 0 : py - 1);
-                            if (!three) {
-                                const int sx = px == 0 ? TX - 1 : 0;
-                                if (sz == 0 || sz == TZ - 1 || sy == 0 || sy == TY - 1) {
-                                    quad = face_row_of(sz, sy) * QROW + (sx == 0 ? 0 : QROW - 1);
-                                    elem = 0;
-                                } else {
-                                    const int v = (sx == 0 ? 0 : 1) * ((TZ - 2) * (TY - 2)) + (sz - 1) * (TY - 2) + (sy - 1);
-                                    quad = NFROW * QROW + v / 3;
-                                    elem = v - (v / 3) * 3;
-                                }
-                            } else {
-                                quad = face_row_of(sz, sy) * QROW + quad;
-                            }
                             const int nbw = (tz2 * g.ty + ty2) * g.cx + tx2;
+                            const int quad = q3 >= 0 ? (q3 * NROWS + sz * TY + sy) * 8 + xg : NQA + xg * NROWS + sz * TY + sy;
                             src[j] = (unsigned)((((int)(target & 1) * g.n_wg + nbw) * NQ + quad) * 16);
-                            dstp[j] = ((pz * LY + py) * LX + px) | (elem << 24) | (three << 28);
+                            dstp[j] = ((pz * LY + py) * LX + px) | (cnt << 14);
                         }
                         unsigned tries = 0;
                         bool pend = false;
 #pragma unroll
                         for (int j = 0; j < NSLOT; ++j) pend = pend || dstp[j] >= 0;
+#ifdef P3_PRESLEEP
+                        asm volatile("s_sleep %0" : : "n"(P3_PRESLEEP));
+#endif
+#ifdef P3_EXP_NOPOLL   // WRONG RESULTS, timing only: no halo at all
+                        pend = false;
+#endif
                         while (pend) {
                             v4f qv[NSLOT];
 #pragma unroll
@@ -358,21 +344,23 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                                 if (dstp[j] >= 0) qv[j] = ldq_sc1(X, src[j]);
 #pragma unroll
                             for (int j = 0; j < NSLOT; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qv[j]) : : "memory");
+#ifdef P3_TRACE
+                            if (tries == 0) { P3_STAMP(2); }
+#endif
                             pend = false;
 #pragma unroll
                             for (int j = 0; j < NSLOT; ++j) {
                                 if (dstp[j] < 0) continue;
+#ifdef P3_EXP_NOWAIT   // WRONG RESULTS, timing only: take whatever is there
+                                if (true) {
+#else
                                 if (__float_as_uint(qv[j].w) == target) {
-                                    float* lp = nxt + (dstp[j] & 0xffffff);
-                                    if (dstp[j] >> 28) {
-                                        const int x0 = (dstp[j] & 0xffffff) % LX;   // px of the first value: values beyond the tile's 64 columns are padding
-                                        lp[0] = qv[j].x;
-                                        if (x0 + 1 <= TX) lp[1] = qv[j].y;
-                                        if (x0 + 2 <= TX) lp[2] = qv[j].z;
-                                    } else {
-                                        const int e = (dstp[j] >> 24) & 3;
-                                        lp[0] = e == 0 ? qv[j].x : (e == 1 ? qv[j].y : qv[j].z);
-                                    }
+#endif
+                                    float* lp = nxt + (dstp[j] & 0x1fff);
+                                    const int cnt = dstp[j] >> 14;
+                                    lp[0] = qv[j].x;
+                                    if (cnt >= 2) lp[1] = qv[j].y;
+                                    if (cnt == 3) lp[2] = qv[j].z;
                                     dstp[j] = -1;
                                 } else {
                                     pend = true;
