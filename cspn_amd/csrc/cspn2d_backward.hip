@@ -177,7 +177,7 @@ __device__ __forceinline__ float4 ld4u(const float* p) {   // 16 bytes, 4-byte a
 }
 __device__ __forceinline__ void st4u(float* p, float4 v) { __builtin_memcpy(p, &v, 16); }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
                                                           const float* __restrict__ sparse, const float* __restrict__ hh,
                                                           const float* __restrict__ ah, const float* __restrict__ a0p,
                                                           const float* __restrict__ gout, float* __restrict__ gg,
@@ -200,33 +200,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dW[k][i] = 0.f;
-    // one level: A_{t+1} (at ap, image order or register order) times the three rows of H_t around the thread's row
-    auto level = [&](const float* __restrict__ ap, bool a_reg_order, const float* __restrict__ ht, bool h_reg_order) {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            const float4 q = *reinterpret_cast<const float4*>(ap + idx);
-            if (a_reg_order) { a[0] = q.x; a[1] = q.z; a[2] = q.w; a[3] = q.y; }   // (c0,c3,c1,c2)
-            else { a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w; }
+    // One level = A_{t+1} times the three rows of H_t around the thread's row.  All ten loads of a level (A, three H groups, the
+    // columns beside the group for the end lanes of a 16-lane row) are issued together and one level AHEAD of the arithmetic, so
+    // that a wave always has a level in flight (issued one by one behind their uses, every load paid a full memory round trip).
+    struct Lvl { float4 a, r[3]; float e0[3], e5[3]; };
+    // t = 0: H_0 = blur (image order), A_1 = adjoint level N-2;  t = 1..N-2: histories;  t = N-1: A_N = dL/dout (image order)
+    auto fetch = [&](int t, Lvl& L, bool first, bool last) {
+        const float* ap = last ? gout : ah + (size_t)(N - 2 - t) * total;
+        const float* ht = first ? blur : hh + (size_t)(t - 1) * total;
+        const bool h_reg_order = !first;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        L.a = z4;
+        if (valid) L.a = *reinterpret_cast<const float4*>(ap + idx);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1
+            const int yy = y + 1 - d;
+            const bool rowin = valid && yy >= 0 && yy < H;
+            const float* row = ht + base + (size_t)(rowin ? yy : 0) * W;
+            L.r[d] = z4;
+            L.e0[d] = L.e5[d] = 0.f;
+            if (rowin) L.r[d] = *reinterpret_cast<const float4*>(row + x);
+            // c3 of the group to the left sits at position 1 of a register-order group, c0 of the group to the right at position 0
+            if (gx == 0 && rowin && x > 0) L.e0[d] = row[h_reg_order ? x - 4 + 1 : x - 1];
+            if (gx == 15 && rowin && x + 4 < W) L.e5[d] = row[x + 4];
         }
+    };
+    auto compute = [&](const Lvl& L, bool first, bool last) {
+        const bool a_reg_order = !last, h_reg_order = !first;
+        float a[4];
+        if (a_reg_order) { a[0] = L.a.x; a[1] = L.a.z; a[2] = L.a.w; a[3] = L.a.y; }   // (c0,c3,c1,c2)
+        else { a[0] = L.a.x; a[1] = L.a.y; a[2] = L.a.z; a[3] = L.a.w; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) dC[i] += a[i];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1: planes 0..2, 3..4, 5..7
-            const int dy = 1 - d, yy = y + dy;
-            const bool rowin = valid && yy >= 0 && yy < H;
-            const float* row = ht + base + (size_t)(rowin ? yy : 0) * W;
             float h[6];   // columns x-1 .. x+4
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowin) q = *reinterpret_cast<const float4*>(row + x);
+            const float4 q = L.r[d];
             if (!h_reg_order) { h[1] = q.x; h[2] = q.y; h[3] = q.z; h[4] = q.w; }
             else { h[1] = q.x; h[2] = q.z; h[3] = q.w; h[4] = q.y; }
-            // the columns beside the group belong to the neighbouring lanes (the next / previous group of the same row); only
-            // the end lanes of a 16-lane row fetch them
+            // the columns beside the group belong to the neighbouring lanes (the next / previous group of the same row); the end
+            // lanes of a 16-lane row have fetched theirs (0 outside the image)
             h[0] = dpp_shr1(h[4]);
             h[5] = dpp_shl1(h[1]);
-            if (gx == 0 && rowin && x > 0) h[0] = row[h_reg_order ? x - 4 + 1 : x - 1];   // c3 of the group to the left: position 1
-            if (gx == 15 && rowin && x + 4 < W) h[5] = row[x + 4];                          // c0 of the group to the right: position 0
-            if (x == 0) h[0] = 0.f;
+            if (gx == 0) h[0] = L.e0[d];
+            if (gx == 15) h[5] = L.e5[d];
             if (x + 4 >= W) h[5] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -245,11 +262,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
             }
         }
     };
-    // t = 0: H_0 = blur (image order), A_1 = adjoint level N-2;  t = 1..N-2: histories;  t = N-1: A_N = dL/dout
-    level(ah + (size_t)(N - 2) * total, true, blur, false);
-#pragma unroll 2
-    for (int t = 1; t < N - 1; ++t) level(ah + (size_t)(N - 2 - t) * total, true, hh + (size_t)(t - 1) * total, true);
-    level(gout, false, hh + (size_t)(N - 2) * total, true);
+    static_assert(N % 2 == 0 && N >= 4, "the level loop alternates two buffers");
+    {
+        Lvl LA, LB;
+        fetch(0, LA, true, false);
+        fetch(1, LB, false, false);
+        compute(LA, true, false);
+        fetch(2, LA, false, false);
+        compute(LB, false, false);
+#pragma unroll 1
+        for (int t = 2; t < N - 2; t += 2) {   // LA holds level t
+            fetch(t + 1, LB, false, false);
+            compute(LA, false, false);
+            fetch(t + 2, LA, false, false);
+            compute(LB, false, false);
+        }
+        fetch(N - 1, LB, false, true);
+        compute(LA, false, false);
+        compute(LB, false, true);
+    }
     if (!valid) return;
     // ---- epilogue: the chain through the fold, the normalisation and the neighbour-sited gather (see the file header)
     const float4 h0q = *reinterpret_cast<const float4*>(blur + idx);
