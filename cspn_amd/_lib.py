@@ -77,6 +77,10 @@ def load():
     lib.cspn_metrics_f32.argtypes = [vp, vp, c_size_t, vp, vp, c_size_t, vp]
     lib.cspn_l1_backward_f32.restype = c_int
     lib.cspn_l1_backward_f32.argtypes = [vp, vp, vp, vp, vp, c_size_t, vp]
+    lib.cspn3d_backward_workspace_bytes.restype = c_size_t
+    lib.cspn3d_backward_workspace_bytes.argtypes = [c_int] * 5
+    lib.cspn3d_backward_f32.restype = c_int
+    lib.cspn3d_backward_f32.argtypes = [vp] * 5 + [c_int] * 6 + [vp, c_size_t, vp]
     lib.cspn_unpool_f32.restype = c_int
     lib.cspn_unpool_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
     lib.cspn_unpool_backward_f32.restype = c_int

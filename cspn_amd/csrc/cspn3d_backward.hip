@@ -1,0 +1,239 @@
+// cspn3d_backward.hip -- backward of the 3x3x3 propagation under the Paddle contract (gates used as given, centre-sited,
+// no centre term, no mask: reference cspn_paddle/README.md:54-56; the op is differentiated by the demo's optimiser,
+// cspn_paddle/demo.py:65-75, `feat` has stop_gradient=False).  Kernel source of the reference op is NOT in the tree
+// (parity unpinned): the arithmetic is the adjoint of oracle/cspn_oracle.c's 3D forward, checked against
+// autograd of the same recurrence in tests/.
+//
+//   forward   H_{t+1}(p) = sum_k g_k(p) H_t(p + off_k),  t = 0 .. n-1,  H_0 = feat,  out = H_n      (zero outside the volume)
+//   adjoint   A_n = dL/dout,   A_t(q) = sum_k g_k(q - off_k) A_{t+1}(q - off_k)                       dL/dfeat = A_0
+//   gates     dL/dg_k(p) = sum_t A_{t+1}(p) H_t(p + off_k)
+//
+// Three kinds of launches, each HBM-bound streaming: the forward steps that keep H_1 .. H_{n-1} (step3d_direct_kernel of
+// cspn3d_stepwise.hip, only when the gate gradient is wanted), n adjoint steps (26 gate planes + A in, A out = 112 B/voxel
+// each, like a forward step), and ONE gate-gradient pass that reads the 2n value volumes and writes the 26 planes once
+// (26 x 4 accumulators per thread).  A single chained call (n = 1, how the Paddle graph uses the op) therefore moves
+// 28 + 28 planes: the adjoint step and the gate-gradient pass, nothing else.
+#include "cspn_common.h"
+
+namespace cspn {
+
+namespace {
+
+__host__ __device__ constexpr int ch3(int k) { return k < 13 ? k : k + 1; }  // skip the centre (index 13)
+
+__device__ __forceinline__ float4 ld4u(const float* p) {   // 16 bytes, 4-byte aligned
+    float4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// voxel index -> (b, z, y, x) of a thread's VEC consecutive voxels
+template <int VEC>
+struct Pos {
+    int b, z, y, x;
+    size_t r;   // offset inside the volume
+    bool ok;
+    __device__ Pos(int B, int D, int H, int W) {
+        const size_t HW = (size_t)H * W, V = (size_t)D * HW, n = (size_t)B * V / VEC;
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        ok = i < n;
+        const size_t idx = (ok ? i : 0) * VEC;
+        b = (int)(idx / V);
+        r = idx - (size_t)b * V;
+        z = (int)(r / HW);
+        const int r2 = (int)(r - (size_t)z * HW);
+        y = r2 / W;
+        x = r2 - y * W;
+    }
+};
+
+// one adjoint step: aout(q) = sum_k g_k(q - off_k) ain(q - off_k); VEC = 4 (W % 4 == 0, 16-byte aligned tensors) or 1
+template <int VEC>
+__global__ __launch_bounds__(256) void adjoint3d_kernel(const float* __restrict__ g, const float* __restrict__ ain,
+                                                         float* __restrict__ aout, int B, int D, int H, int W) {
+    const Pos<VEC> p(B, D, H, W);
+    if (!p.ok) return;
+    const size_t HW = (size_t)H * W, V = (size_t)D * HW;
+    const float* ab = ain + (size_t)p.b * V;
+    const float* gb = g + (size_t)p.b * 26 * V;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {   // source rows (z - dz, y - dy)
+        const int dz = 1 - n / 3, dy = 1 - n % 3;
+        const int zz = p.z - dz, yy = p.y - dy;
+        if (zz < 0 || zz >= D || yy < 0 || yy >= H) continue;
+        const size_t ro = ((size_t)zz * H + yy) * W;
+        float a[VEC + 2];   // ain at columns x-1 .. x+VEC of the source row
+        if (VEC == 4) {
+            const float4 c = *reinterpret_cast<const float4*>(ab + ro + p.x);
+            a[1] = c.x; a[2] = c.y; a[3] = c.z; a[4] = c.w;
+        } else {
+            a[1] = ab[ro + p.x];
+        }
+        a[0] = p.x > 0 ? ab[ro + p.x - 1] : 0.f;
+        a[VEC + 1] = p.x + VEC < W ? ab[ro + p.x + VEC] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {   // dx = 1 - t: the source voxel of column x + i is x + i - dx
+            const int c27 = n * 3 + t;
+            if (c27 == 13) continue;
+            const int k = c27 < 13 ? c27 : c27 - 1;
+            const int dx = 1 - t;
+            const float* gp = gb + (size_t)k * V + ro + p.x - dx;
+            float w[VEC];
+            if (VEC == 4 && p.x - dx >= 0 && p.x - dx + 3 < W) {
+                const float4 q = ld4u(gp);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int xs = p.x + i - dx;
+                    w[i] = (xs >= 0 && xs < W) ? gp[i] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w[i], a[1 + i - dx], acc[i]);
+        }
+    }
+    float* o = aout + (size_t)p.b * V + p.r;
+    if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else o[0] = acc[0];
+}
+
+// dL/dg_k(p) = sum_t A_{t+1}(p) H_t(p + off_k).  Level t: H_0 = feat, H_t = hist + (t-1) total; A_n = gout,
+// A_t = ahist + (t-1) total (t = 1 .. n-1)
+template <int VEC>
+__global__ __launch_bounds__(256) void gate_grad3d_kernel(const float* __restrict__ feat, const float* __restrict__ hist,
+                                                           const float* __restrict__ ahist, const float* __restrict__ gout,
+                                                           float* __restrict__ gg, int B, int D, int H, int W, int n_iter) {
+    const Pos<VEC> p(B, D, H, W);
+    if (!p.ok) return;
+    const size_t HW = (size_t)H * W, V = (size_t)D * HW, total = (size_t)B * V;
+    float acc[26][VEC];
+#pragma unroll
+    for (int k = 0; k < 26; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    const size_t vox = (size_t)p.b * V + p.r;
+#pragma unroll 1
+    for (int t = 0; t < n_iter; ++t) {
+        const float* ht = (t == 0 ? feat : hist + (size_t)(t - 1) * total) + (size_t)p.b * V;
+        const float* at = t == n_iter - 1 ? gout : ahist + (size_t)t * total;   // A_{t+1}
+        float a[VEC];
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(at + vox);
+            a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w;
+        } else {
+            a[0] = at[vox];
+        }
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {   // neighbour rows (z + dz, y + dy)
+            const int dz = 1 - n / 3, dy = 1 - n % 3;
+            const int zz = p.z + dz, yy = p.y + dy;
+            float h[VEC + 2];
+#pragma unroll
+            for (int i = 0; i < VEC + 2; ++i) h[i] = 0.f;
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H) {
+                const float* row = ht + ((size_t)zz * H + yy) * W;
+                if (VEC == 4) {
+                    const float4 c = *reinterpret_cast<const float4*>(row + p.x);
+                    h[1] = c.x; h[2] = c.y; h[3] = c.z; h[4] = c.w;
+                } else {
+                    h[1] = row[p.x];
+                }
+                if (p.x > 0) h[0] = row[p.x - 1];
+                if (p.x + VEC < W) h[VEC + 1] = row[p.x + VEC];
+            }
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int c27 = n * 3 + t3;
+                if (c27 == 13) continue;
+                const int k = c27 < 13 ? c27 : c27 - 1;
+                const int dx = 1 - t3;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(a[i], h[1 + i + dx], acc[k][i]);
+            }
+        }
+    }
+    float* o = gg + (size_t)p.b * 26 * V + p.r;
+#pragma unroll
+    for (int k = 0; k < 26; ++k) {
+        if (VEC == 4) *reinterpret_cast<float4*>(o + (size_t)k * V) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        else o[(size_t)k * V] = acc[k][0];
+    }
+}
+
+// forward step for shapes / alignments the 16-byte kernel of cspn3d_stepwise.hip does not take
+__global__ __launch_bounds__(256) void step3d_scalar_kernel(const float* __restrict__ g, const float* __restrict__ hin,
+                                                             float* __restrict__ hout, int B, int D, int H, int W) {
+    const Pos<1> p(B, D, H, W);
+    if (!p.ok) return;
+    const size_t HW = (size_t)H * W, V = (size_t)D * HW;
+    const float* hb = hin + (size_t)p.b * V;
+    const float* gb = g + (size_t)p.b * 26 * V + p.r;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 26; ++k) {
+        const int c = ch3(k);
+        const int zz = p.z + 1 - c / 9, yy = p.y + 1 - (c / 3) % 3, xx = p.x + 1 - c % 3;
+        if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+            acc = fmaf(gb[(size_t)k * V], hb[((size_t)zz * H + yy) * W + xx], acc);
+    }
+    hout[(size_t)p.b * V + p.r] = acc;
+}
+
+}  // namespace
+
+// levels kept: H_1 .. H_{n-1} and A_1 .. A_{n-1} (A_0 goes to grad_feat, or to one more volume when the caller does not want it)
+size_t backward3d_workspace(int B, int D, int H, int W, int n_iter) {
+    const size_t total = (size_t)B * D * H * W;
+    return (2 * (size_t)(n_iter > 0 ? n_iter - 1 : 0) + 1) * total * sizeof(float);
+}
+
+int step3d_direct(const float* g, const float* hin, float* hout, int B, int D, int H, int W, hipStream_t st);   // cspn3d_stepwise.hip
+
+int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W,
+               int n_iter, void* ws, hipStream_t st) {
+    const size_t total = (size_t)B * D * H * W;
+    float* hist = (float*)ws;                                  // H_1 .. H_{n-1}
+    float* ahist = hist + (size_t)(n_iter - 1) * total;        // A_1 .. A_{n-1}
+    float* a0 = gf ? gf : ahist + (size_t)(n_iter - 1) * total;
+    const bool vec = (W % 4) == 0 &&
+                     ((((uintptr_t)g | (uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gg | (uintptr_t)gf | (uintptr_t)ws) & 15u) == 0);
+    const unsigned blocks = (unsigned)((total / (vec ? 4 : 1) + 255) / 256);
+    if (gg) {   // the value levels the gate gradient multiplies with
+        const float* src = feat;
+        for (int t = 1; t < n_iter; ++t) {
+            float* dst = hist + (size_t)(t - 1) * total;
+            if (vec) {
+                if (int e = step3d_direct(g, src, dst, B, D, H, W, st)) return e;
+            } else {
+                hipLaunchKernelGGL(step3d_scalar_kernel, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
+            }
+            src = dst;
+        }
+        if (int e = check_launch("3D forward levels")) return e;
+    }
+    // adjoint levels A_{n-1} .. A_1 (kept only if the gate gradient needs them: otherwise two volumes would do, but the
+    // workspace is sized for the general call) and A_0
+    const float* src = gout;
+    for (int t = n_iter - 1; t >= 0; --t) {
+        float* dst = t == 0 ? a0 : ahist + (size_t)(t - 1) * total;
+        if (t == 0 && !gf) break;   // A_0 is only the feature gradient
+        if (vec) hipLaunchKernelGGL(adjoint3d_kernel<4>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
+        else hipLaunchKernelGGL(adjoint3d_kernel<1>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
+        src = dst;
+    }
+    if (int e = check_launch("adjoint3d_kernel")) return e;
+    if (gg) {
+        if (vec)
+            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+        else
+            hipLaunchKernelGGL(gate_grad3d_kernel<1>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+        if (int e = check_launch("gate_grad3d_kernel")) return e;
+    }
+    return 0;
+}
+
+}  // namespace cspn

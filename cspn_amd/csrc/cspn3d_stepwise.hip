@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void step3d_direct_kernel(const float* __restr
     *reinterpret_cast<float4*>(hout + idx) = acc;
 }
 
+// one step of the Paddle contract for other files (the backward keeps the value levels): W % 4 == 0, 16-byte aligned tensors
+int step3d_direct(const float* g, const float* hin, float* hout, int B, int D, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)B * D * H * W;
+    hipLaunchKernelGGL(step3d_direct_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, g, hin, hout, B, D, H, W / 4);
+    return 0;
+}
+
 static bool direct3d_ok(const float* g, const float* feat, const float* sparse, const float* out, int W, int norm,
                         const void* ws) {
     return norm == CSPN_NORM_NONE && sparse == nullptr && (W % 4) == 0 &&

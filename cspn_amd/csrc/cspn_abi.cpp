@@ -204,4 +204,32 @@ int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* s
     return stepwise3d_forward(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, ws, st, algo);
 }
 
+size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    return backward3d_workspace(B, D, H, W, n_iter);
+}
+
+int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat, int B,
+                        int D, int H, int W, int n_iter, int norm_type, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d D=%d H=%d W=%d", B, D, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if ((long long)B * D * H * W > 0x7fffffffLL / 27) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
+    if (norm_type != CSPN_NORM_NONE) {
+        set_error("the 3D backward covers the Paddle contract only (norm_type NONE: gates used as given, no mask)");
+        return CSPN_E_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = check_common(gate, feat, grad_out, n_iter, norm_type, ws, ws_bytes, n_iter == 0 ? 0 : backward3d_workspace(B, D, H, W, n_iter))) return e;
+    if (!grad_gate && !grad_feat) return 0;
+    const size_t bytes = sizeof(float) * (size_t)B * D * H * W;
+    if (n_iter == 0) {   // identity: dL/dfeat = dL/dout, the gates are not used
+        hipError_t e = hipSuccess;
+        if (grad_feat) e = hipMemcpyAsync(grad_feat, grad_out, bytes, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && grad_gate) e = hipMemsetAsync(grad_gate, 0, 26 * bytes, st);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync / hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+    }
+    return backward3d(gate, feat, grad_out, grad_gate, grad_feat, B, D, H, W, n_iter, ws, st);
+}
+
 }  // extern "C"

@@ -39,6 +39,11 @@ size_t persistent3d_workspace(int B, int D, int H, int W);
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                          hipStream_t st);
 
+// ---- backward of the 3D op, Paddle contract only (cspn3d_backward.hip) ----
+size_t backward3d_workspace(int B, int D, int H, int W, int n_iter);
+int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W, int n_iter,
+               void* ws, hipStream_t st);
+
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);

@@ -186,11 +186,60 @@ def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs", alg
     return (out, ws) if _return_ws else out
 
 
+def cspn3d_backward(gate, feat, grad_out, n_iter=1, need_gate=True, need_feat=True):
+    """Gradient of cspn3d_forward(gate, feat, None, n_iter, 'none') -- the Paddle contract, the op the reference demo's
+    optimiser differentiates (cspn_paddle/demo.py:65-75) -- w.r.t. gate and feat, in the HIP engine.
+    -> (grad_gate [B,26,D,H,W] or None, grad_feat [B,1,D,H,W] or None)"""
+    lib = _lib.load()
+    if gate.dim() != 5 or gate.shape[1] != 26:
+        raise ValueError("gate must be [B,26,D,H,W], got %s" % (tuple(gate.shape),))
+    B, _, D, H, W = gate.shape
+    g = _prep(gate, "gate")
+    h = _prep(feat, "feat", (B, 1, D, H, W))
+    go = _prep(grad_out, "grad_out", (B, 1, D, H, W))
+    gg = torch.empty_like(g) if need_gate else None
+    gf = torch.empty_like(h) if need_feat else None
+    if B == 0 or not (need_gate or need_feat):
+        return gg, gf
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn3d_backward_workspace_bytes(B, D, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        rc = lib.cspn3d_backward_f32(g.data_ptr(), h.data_ptr(), go.data_ptr(), gg.data_ptr() if gg is not None else None,
+                                     gf.data_ptr() if gf is not None else None, B, D, H, W, int(n_iter),
+                                     _lib.NORM_TYPES["none"], ws.data_ptr(), ws_bytes, stream)
+    _lib.check(rc, "cspn3d_backward_f32")
+    return gg, gf
+
+
+class _AffinityPropagateFunction(torch.autograd.Function):
+    """n_iter chained propagation steps with the same gates, one input channel; differentiable w.r.t. both arguments."""
+
+    @staticmethod
+    def forward(ctx, x, gate_weight, n_iter):
+        ctx.n_iter = int(n_iter)
+        ctx.save_for_backward(x, gate_weight)
+        if x.dim() == 4:
+            return cspn2d_forward(gate_weight, x, None, n_iter, "none")
+        return cspn3d_forward(gate_weight, x, None, n_iter, "none")
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, gate_weight = ctx.saved_tensors
+        need_x, need_g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if x.dim() == 4:
+            gg, gx = cspn2d_backward(gate_weight, x, None, grad_out, ctx.n_iter, "none", need_g, need_x)
+        else:
+            gg, gx = cspn3d_backward(gate_weight, x, grad_out, ctx.n_iter, need_g, need_x)
+        return gx, gg, None
+
+
 def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
     """Mirror of fluid.layers.affinity_propagate (reference cspn_paddle/demo.py:41-43,50-52;
     contract cspn_paddle/README.md:54-56): input [N,C,...], gate_weight [N,3**d-1,...] already
     normalised over the channel dim by the caller, shared across the C input channels.
-    d = 2 or 3.  n_iter > 1 fuses that many chained calls (demo.py:39,50)."""
+    d = 2 or 3.  n_iter > 1 fuses that many chained calls (demo.py:39,50).  Differentiable w.r.t. input and
+    gate_weight like the reference op (the demo trains through it, demo.py:65-75)."""
     if kernel_size != 3:
         raise ValueError("only kernel_size == 3 is supported (reference cspn_paddle/demo.py:90)")
     d = input.dim() - 2
@@ -202,7 +251,9 @@ def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
     outs = []
     for c in range(C):  # gates shared across channels (README.md:56)
         x = input[:, c:c + 1].contiguous()
-        if d == 2:
+        if torch.is_grad_enabled() and (x.requires_grad or gate_weight.requires_grad):
+            outs.append(_AffinityPropagateFunction.apply(x, gate_weight, n_iter))
+        elif d == 2:
             outs.append(cspn2d_forward(gate_weight, x, None, n_iter, "none"))
         else:
             outs.append(cspn3d_forward(gate_weight, x, None, n_iter, "none"))

@@ -132,6 +132,15 @@ int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* s
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
                             void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
+/* Backward of the 3D op under the Paddle contract (norm_type CSPN_NORM_NONE, no mask): the reference op is differentiated by
+ * the demo's optimiser (cspn_paddle/demo.py:65-75, `feat` has stop_gradient=False).  grad_out [B,1,D,H,W];
+ * grad_gate [B,26,D,H,W] and grad_feat [B,1,D,H,W] are outputs, either may be NULL.  n_iter chained steps with the same
+ * gates are differentiated as one op (n_iter = 1 is the single fluid.layers.affinity_propagate call). */
+size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
+int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat,
+                        int B, int D, int H, int W, int n_iter, int norm_type,
+                        void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
 /* ---- the steps right next to the path, on the device ----
  * cspn_metrics_f32: reference cspn_pytorch/utils.py:19-47 (evaluate_error) and loss.py:16-23 (Wighted_L1_Loss = MAE
  * over gt > 1e-4) as one fused masked reduction over n elements.  out12 (device, 12 floats):

@@ -66,3 +66,44 @@ def cspn2d_backward_oracle(guidance, blur, sparse, grad_out, n_iter, norm_type="
         if norm_type == "8sum_abs":
             gg = gg * np.sign(g)
     return hs[-1][:, None], gg.astype(np.float32), grad_blur[:, None].astype(np.float32)
+
+
+# ---- 3D, Paddle contract (gates used as given, no mask): adjoint of oracle/cspn_oracle.c's cspn3d_one with norm_type 2 ----
+OFF3 = [(1 - f, 1 - t, 1 - l) for f in range(3) for t in range(3) for l in range(3) if (f, t, l) != (1, 1, 1)]
+
+
+def _shift3(a, dz, dy, dx):
+    """out(p) = a(p + (dz,dy,dx)), zero outside; a: [B,D,H,W]"""
+    B, D, H, W = a.shape
+    pad = np.zeros((B, D + 2, H + 2, W + 2), a.dtype)
+    pad[:, 1:-1, 1:-1, 1:-1] = a
+    return pad[:, 1 + dz:1 + dz + D, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+
+
+def cspn3d_forward_levels(gate, feat, n_iter, dtype=np.float32):
+    """[H_0 .. H_n] of H_{t+1}(p) = sum_k g_k(p) H_t(p + off_k) (cspn_oracle.c cspn3d_one, norm_type 2)"""
+    g = np.asarray(gate, dtype)
+    hs = [np.asarray(feat, dtype)[:, 0]]
+    for _ in range(n_iter):
+        acc = np.zeros_like(hs[-1])
+        for k, (dz, dy, dx) in enumerate(OFF3):
+            acc = acc + g[:, k] * _shift3(hs[-1], dz, dy, dx)
+        hs.append(acc.astype(dtype))
+    return hs
+
+
+def cspn3d_backward_oracle(gate, feat, grad_out, n_iter, dtype=np.float32):
+    """-> (grad_gate [B,26,D,H,W], grad_feat [B,1,D,H,W]) of the n_iter-step 3D propagation with the gates as given.
+    The reference op's source is absent (parity unpinned); this is the adjoint of the oracle's forward, pinned
+    in tests/test_oracle.py against torch autograd through the same recurrence."""
+    g = np.asarray(gate, dtype)
+    hs = cspn3d_forward_levels(gate, feat, n_iter, dtype)
+    A = np.asarray(grad_out, dtype)[:, 0].copy()
+    dG = np.zeros_like(g)
+    for t in range(n_iter - 1, -1, -1):
+        An = np.zeros_like(A)
+        for k, (dz, dy, dx) in enumerate(OFF3):
+            dG[:, k] += A * _shift3(hs[t], dz, dy, dx)
+            An += _shift3(g[:, k] * A, -dz, -dy, -dx)
+        A = An.astype(dtype)
+    return dG, A[:, None]

@@ -1,0 +1,158 @@
+"""Backward of the 3D op under the Paddle contract (the reference op is differentiable, the demo's optimiser
+back-propagates through it, cspn_paddle/demo.py:65-75).  The reference kernel is not in the tree (parity unpinned):
+CPU: oracle/backward.py's adjoint against torch autograd through a plain torch statement of the same recurrence, and its
+     forward levels against oracle/cspn_oracle.c.
+GPU: the HIP kernels through the C ABI / the autograd mirror of fluid.layers.affinity_propagate against the oracle, and at
+     config 5's full size through properties (linearity in grad_out, <A, dH> pairing, n = 1 closed forms)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cspn3d_oracle
+from oracle.backward import OFF3, cspn3d_backward_oracle, cspn3d_forward_levels
+
+GTOL = 2e-4   # relative to max|grad|, as for the 2D backward
+
+
+def _inputs(B, D, H, W, seed, signed=False):
+    gen = torch.Generator().manual_seed(seed)
+    g = torch.rand(B, 26, D, H, W, generator=gen)
+    if signed:
+        g = g - 0.3
+    g = g / g.abs().sum(1, keepdim=True)   # demo.py:24,47-49: divided by the channel sum of |.|
+    h = torch.rand(B, 1, D, H, W, generator=gen)
+    go = torch.randn(B, 1, D, H, W, generator=gen)
+    return g, h, go
+
+
+def _torch_forward(g, h, n_iter):
+    """H_{t+1}(p) = sum_k g_k(p) H_t(p + off_k), zero outside; plain torch ops (autograd-able)"""
+    B, _, D, H, W = g.shape
+    x = h[:, 0]
+    for _ in range(n_iter):
+        pad = torch.nn.functional.pad(x, (1, 1, 1, 1, 1, 1))
+        acc = 0
+        for k, (dz, dy, dx) in enumerate(OFF3):
+            acc = acc + g[:, k] * pad[:, 1 + dz:1 + dz + D, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+        x = acc
+    return x[:, None]
+
+
+def _err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("B,D,H,W,N,signed", [(2, 4, 5, 7, 1, False), (1, 3, 6, 8, 4, True), (1, 5, 4, 12, 12, False)])
+def test_oracle_3d_backward_vs_torch_autograd(B, D, H, W, N, signed):
+    g, h, go = _inputs(B, D, H, W, seed=3 + N, signed=signed)
+    # the forward levels of the numpy restatement are the C oracle's (norm 'none')
+    hs = cspn3d_forward_levels(g.numpy(), h.numpy(), N)
+    ref = cspn3d_oracle(g.numpy(), h.numpy(), None, N, "none")
+    assert _err(hs[-1][:, None], ref) <= 1e-6
+    gt, ht = g.clone().double().requires_grad_(True), h.clone().double().requires_grad_(True)
+    _torch_forward(gt, ht, N).backward(go.double())
+    dG, dF = cspn3d_backward_oracle(g.numpy(), h.numpy(), go.numpy(), N)
+    assert _err(dG, gt.grad.numpy()) <= 1e-5 and _err(dF, ht.grad.numpy()) <= 1e-5
+
+
+def test_abi_exports_3d_backward_and_rejects_normalising_modes():
+    import ctypes
+    import cspn_amd
+    lib = cspn_amd.load()
+    assert lib.cspn3d_backward_workspace_bytes(2, 4, 8, 16, 3) == (2 * 2 + 1) * 2 * 4 * 8 * 16 * 4
+    assert lib.cspn3d_backward_workspace_bytes(2, 4, 8, 16, 1) == 2 * 4 * 8 * 16 * 4
+    one = ctypes.c_void_p(256)   # never dereferenced: the mode is refused before any launch
+    rc = lib.cspn3d_backward_f32(one, one, one, one, one, 1, 2, 2, 4, 1, 0, one, 1 << 20, None)
+    assert rc != 0 and b"Paddle contract" in lib.cspn_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,H,W,N,signed", [(2, 4, 5, 8, 1, False), (1, 3, 6, 7, 4, True), (1, 9, 17, 72, 3, False),
+                                               (2, 6, 10, 37, 12, False)])
+def test_hip_3d_backward_vs_oracle(B, D, H, W, N, signed):
+    import cspn_amd
+    g, h, go = _inputs(B, D, H, W, seed=11 + N, signed=signed)
+    dG, dF = cspn3d_backward_oracle(g.numpy(), h.numpy(), go.numpy(), N)
+    gg, gf = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N)
+    assert _err(gg.cpu().numpy(), dG) <= GTOL and _err(gf.cpu().numpy(), dF) <= GTOL
+    # either output alone
+    gg1, none = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N, need_feat=False)
+    none2, gf1 = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N, need_gate=False)
+    assert none is None and none2 is None and torch.equal(gg1, gg) and torch.equal(gf1, gf)
+
+
+@pytest.mark.gpu
+def test_affinity_propagate_mirror_is_differentiable_like_the_paddle_op():
+    """chained single-step calls (how the reference graph uses the op, demo.py:50-52) and the fused n_iter call give the same
+    gradients, and both match autograd through plain torch ops"""
+    import cspn_amd
+    B, D, H, W, N = 2, 6, 9, 16, 3
+    g, h, go = _inputs(B, D, H, W, seed=5)
+    gt, ht = g.clone().double().requires_grad_(True), h.clone().double().requires_grad_(True)
+    _torch_forward(gt, ht, N).backward(go.double())
+    g1, h1 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    x = h1
+    for _ in range(N):
+        x = cspn_amd.affinity_propagate(x, g1, 3)
+    x.backward(go.cuda())
+    g2, h2 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+    y = cspn_amd.affinity_propagate(h2, g2, 3, n_iter=N)
+    y.backward(go.cuda())
+    assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
+    for got_g, got_h in ((g1.grad, h1.grad), (g2.grad, h2.grad)):
+        assert _err(got_g.cpu().numpy(), gt.grad.numpy()) <= GTOL and _err(got_h.cpu().numpy(), ht.grad.numpy()) <= GTOL
+    # 2D flavour of the op (8 gates), two input channels sharing the gates (README.md:56)
+    gen = torch.Generator().manual_seed(9)
+    g8 = torch.rand(2, 8, 12, 20, generator=gen); g8 = g8 / g8.sum(1, keepdim=True)
+    x2 = torch.rand(2, 2, 12, 20, generator=gen)
+    gd, xd = g8.cuda().requires_grad_(True), x2.cuda().requires_grad_(True)
+    out = cspn_amd.affinity_propagate(xd, gd, 3, n_iter=2)
+    out.sum().backward()
+    assert gd.grad is not None and xd.grad is not None and torch.isfinite(gd.grad).all() and torch.isfinite(xd.grad).all()
+    # mass conservation of the adjoint: sum over voxels of dL/dx equals sum_p (A^T 1)(p); with interior-normalised gates and
+    # grad_out = 1 every interior voxel receives exactly the sum of the gates pointing at it -- check against plain torch
+    gt2, xt2 = g8.clone().double().requires_grad_(True), x2.clone().double().requires_grad_(True)
+    acc = []
+    for c in range(2):
+        v = xt2[:, c]
+        for _ in range(2):
+            pad = torch.nn.functional.pad(v, (1, 1, 1, 1))
+            DY = [1, 1, 1, 0, 0, -1, -1, -1]; DX = [1, 0, -1, 1, -1, 1, 0, -1]
+            v = sum(gt2[:, k] * pad[:, 1 + DY[k]:1 + DY[k] + 12, 1 + DX[k]:1 + DX[k] + 20] for k in range(8))
+        acc.append(v)
+    torch.stack(acc, 1).sum().backward()
+    assert _err(gd.grad.cpu().numpy(), gt2.grad.numpy()) <= GTOL and _err(xd.grad.cpu().numpy(), xt2.grad.numpy()) <= GTOL
+
+
+@pytest.mark.gpu
+def test_hip_3d_backward_config5_size_properties():
+    """BASELINE config 5's volume (one image of the batch of 4): size-independent properties of the adjoint"""
+    import cspn_amd
+    B, D, H, W, N = 1, 32, 160, 608, 12
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device="cuda"); g /= g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device="cuda")
+    a = torch.randn(B, 1, D, H, W, generator=gen, device="cuda")
+    b = torch.randn(B, 1, D, H, W, generator=gen, device="cuda")
+    ga, fa = cspn_amd.cspn3d_backward(g, h, a, N)
+    gb, fb = cspn_amd.cspn3d_backward(g, h, b, N)
+    gc, fc = cspn_amd.cspn3d_backward(g, h, 2.0 * a - 0.5 * b, N)
+    assert torch.isfinite(gc).all() and torch.isfinite(fc).all()
+    assert float((gc - (2.0 * ga - 0.5 * gb)).abs().max() / gc.abs().max()) <= GTOL
+    assert float((fc - (2.0 * fa - 0.5 * fb)).abs().max() / fc.abs().max()) <= GTOL
+    # the op is linear in feat: <grad_out, forward(feat)> == <dL/dfeat, feat>  (adjoint pairing, fp64 sums)
+    out = cspn_amd.cspn3d_forward(g, h, None, N, "none")
+    lhs = float((a.double() * out.double()).sum()); rhs = float((fa.double() * h.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), float((a.double().abs() * out.double().abs()).sum()) * 1e-3)
+    # and linear in each gate plane given the others' levels: sum_k <dL/dg_k, g_k> == n_iter * <grad_out, out>
+    # (Euler: out is homogeneous of degree n_iter in the gates)
+    euler = float((ga.double() * g.double()).sum())
+    assert abs(euler - N * lhs) <= 2e-4 * max(abs(N * lhs), float((ga.double().abs() * g.double()).sum()) * 1e-3)
+    # n = 1 closed form: dL/dg_k(p) = grad_out(p) feat(p + off_k), spot-checked on a few planes
+    g1, f1 = cspn_amd.cspn3d_backward(g, h, a, 1)
+    pad = torch.nn.functional.pad(h[:, 0], (1, 1, 1, 1, 1, 1))
+    for k in (0, 12, 13, 25):
+        dz, dy, dx = OFF3[k]
+        want = a[:, 0] * pad[:, 1 + dz:1 + dz + D, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+        assert torch.allclose(g1[:, k], want, rtol=1e-6, atol=1e-7)
