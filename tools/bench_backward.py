@@ -16,12 +16,41 @@ sys.path.insert(0, ROOT)
 import cspn_amd  # noqa: E402
 
 
+def vol3d(a):
+    """cspn3d_backward_f32 at config 5 (4 x 32x160x608): the single chained call (n_iter 1, how the Paddle graph uses the op)
+    and the fused 12-step op.  Algorithmic bytes of a gradient that touches every tensor once: gate 104 + feat 4 + grad_out 4
+    in, grad_gate 104 + grad_feat 4 out = 220 B/voxel."""
+    B, D, H, W = (a.batch if a.batch != 16 else 4), 32, 160, 608
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device="cuda"); g /= g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device="cuda")
+    go = torch.randn(B, 1, D, H, W, generator=gen, device="cuda")
+    vox = B * D * H * W
+    for N in (1, 12):
+        for _ in range(2):
+            cspn_amd.cspn3d_backward(g, h, go, N)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.steps):
+            cspn_amd.cspn3d_backward(g, h, go, N)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps
+        print(json.dumps({"op": "cspn3d_backward_f32", "B": B, "D": D, "H": H, "W": W, "n_iter": N, "ms_per_call": round(ms, 3),
+                          "Mvox_iters_per_s": round(vox * N / ms / 1e3, 1), "algorithmic_bytes": vox * 220,
+                          "roofline_frac": round(vox * 220 / (ms * 1e-3) / 8e12, 4),
+                          "note": "n_iter - 1 forward steps keeping the levels + n_iter adjoint steps (112 B/voxel each) + one gate-gradient pass"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--sparse", action="store_true")
+    ap.add_argument("--vol3d", action="store_true", help="the 3D backward (Paddle contract) at BASELINE config 5's volume")
     a = ap.parse_args()
+    if a.vol3d:
+        return vol3d(a)
     B, H, W, N = a.batch, 304, 1216, 24
     gen = torch.Generator(device="cuda").manual_seed(1)
     g = torch.randn(B, 8, H, W, generator=gen, device="cuda")
