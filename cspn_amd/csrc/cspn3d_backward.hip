@@ -13,6 +13,8 @@
 // each, like a forward step), and ONE gate-gradient pass that reads the 2n value volumes and writes the 26 planes once
 // (26 x 4 accumulators per thread).  A single chained call (n = 1, how the Paddle graph uses the op) therefore moves
 // 28 + 28 planes: the adjoint step and the gate-gradient pass, nothing else.
+#include <cstdlib>
+
 #include "cspn_common.h"
 
 namespace cspn {
@@ -185,10 +187,16 @@ __global__ __launch_bounds__(256) void step3d_scalar_kernel(const float* __restr
 
 }  // namespace
 
-// levels kept: H_1 .. H_{n-1} and A_1 .. A_{n-1} (A_0 goes to grad_feat, or to one more volume when the caller does not want it)
-size_t backward3d_workspace(int B, int D, int H, int W, int n_iter) {
+// levels kept: H_1 .. H_{n-1} and A_1 .. A_{n-1} (A_0 goes to grad_feat, or to one more volume when the caller does not want
+// it), then the workspace of the persistent kernel (fused sweeps, n >= 3)
+static size_t levels_bytes(int B, int D, int H, int W, int n_iter) {
     const size_t total = (size_t)B * D * H * W;
-    return (2 * (size_t)(n_iter > 0 ? n_iter - 1 : 0) + 1) * total * sizeof(float);
+    const size_t b = (2 * (size_t)(n_iter > 0 ? n_iter - 1 : 0) + 1) * total * sizeof(float);
+    return (b + 255) & ~(size_t)255;
+}
+
+size_t backward3d_workspace(int B, int D, int H, int W, int n_iter) {
+    return levels_bytes(B, D, H, W, n_iter) + persistent3d_workspace(B, D, H, W);
 }
 
 int step3d_direct(const float* g, const float* hin, float* hout, int B, int D, int H, int W, hipStream_t st);   // cspn3d_stepwise.hip
@@ -202,6 +210,26 @@ int backward3d(const float* g, const float* feat, const float* gout, float* gg, 
     const bool vec = (W % 4) == 0 &&
                      ((((uintptr_t)g | (uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gg | (uintptr_t)gf | (uintptr_t)ws) & 15u) == 0);
     const unsigned blocks = (unsigned)((total / (vec ? 4 : 1) + 255) / 256);
+    // fused sweeps: the persistent kernel (gates read once per sweep, resident in registers across the steps) in its
+    // level-keeping and transposed variants -- forward H_1 .. H_{n-1} (n - 1 steps, the last one "out" = H_{n-1}), adjoint
+    // A_{n-1} .. A_0 (n steps).  One launch per step otherwise.
+    void* pws = (char*)ws + levels_bytes(B, D, H, W, n_iter);
+    static const bool stepwise_only = getenv("CSPN_3D_BWD_STEPWISE") != nullptr;   // A/B switch
+    const bool fused = vec && !stepwise_only && n_iter >= 3 && persistent3d_supported(B, D, H, W, n_iter - 1) &&
+                       persistent3d_supported(B, D, H, W, n_iter);
+    if (fused) {
+        if (gg)
+            if (int e = persistent3d_run(g, feat, hist + (size_t)(n_iter - 2) * total, hist, -1, 1, false, B, D, H, W, n_iter - 1, pws, st))
+                return e;
+        // step it of the adjoint run produces A_{n-it}: volume n - it - 1 of ahist; the last one (A_0) is its "out"
+        if (gf || gg)
+            if (int e = persistent3d_run(g, gout, a0, ahist, n_iter - 1, -1, true, B, D, H, W, n_iter, pws, st)) return e;
+        if (gg) {
+            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+            if (int e = check_launch("gate_grad3d_kernel")) return e;
+        }
+        return 0;
+    }
     if (gg) {   // the value levels the gate gradient multiplies with
         const float* src = feat;
         for (int t = 1; t < n_iter; ++t) {

@@ -35,6 +35,7 @@ struct Geo3 {
     int S;                   // owned x-extent of a chunk
     int nchunk;              // chunks per volume
     int n_wg;                // workgroups launched (>= tz * ty * cx)
+    int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -78,10 +79,15 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
     return v;
 }
 
-template <bool TAGGED>
+// ADJ: the transposed operator A_t(q) = sum_k g_k(q - off_k) A_{t+1}(q - off_k) of the backward, i.e. the same propagation with the
+// gates w_j(q) = g_{opp(j)}(q + off_j) (off_{opp(j)} = -off_j): only the chunk prologue differs, it reads plane opp(j) shifted by
+// off_j (4-byte aligned 16-byte loads; a quad that sticks out of the volume by its first / last element is read aligned and
+// shifted in the registers).  levels != nullptr: every step but the last also stores its owned voxels (the level history
+// the gate gradient multiplies with).
+template <bool TAGGED, bool ADJ>
 __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
-                                                                 float* __restrict__ out, float* __restrict__ scratch,
-                                                                 unsigned* __restrict__ sync, Geo3 g) {
+                                                                 float* __restrict__ out, float* __restrict__ levels,
+                                                                 float* __restrict__ scratch, unsigned* __restrict__ sync, Geo3 g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * LTILE];
     __shared__ int s_bail;
     unsigned* flags = sync;                  // [MAX_WG] per-tile step flags
@@ -163,6 +169,20 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
                     const float* gk = gate + ((size_t)b * 26 + k) * V;
+                    if (ADJ) {
+                        const int c27 = k < 13 ? k : k + 1, dz = 1 - c27 / 9, dy = 1 - (c27 / 3) % 3, dx = 1 - c27 % 3;
+                        const int ko = (26 - c27) < 13 ? (26 - c27) : (26 - c27) - 1;   // the plane of the opposite offset
+                        const float* gko = gate + ((size_t)b * 26 + ko) * V;
+                        const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
+                        const int sh = ((dz * g.H + dy) * g.W) * 4;
+                        // first / last element outside the volume: read the aligned quad, shift afterwards
+                        const int e0 = (dx < 0 && x == 0) || (dx > 0 && x + 4 == g.W) ? 0 : dx * 4;
+                        const int e1 = (dx < 0 && x + 4 == 0) || (dx > 0 && x + 8 == g.W) ? 0 : dx * 4;
+                        const unsigned a0 = in0 && rowok ? (unsigned)((int)voff + sh + e0) : 0u;
+                        const unsigned a1 = in1 && rowok ? (unsigned)((int)voff + 16 + sh + e1) : 0u;
+                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(a0), "s"(gko) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(a1), "s"(gko) : "memory");
+                    } else {
 #if defined(P3_EXP_NT)   // timing experiments (profiles/r02_perf_notes.md): the nontemporal hint costs 10 % of the forward
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
 #endif
+                    }
                 }
                 {   // level 0 into both LDS buffers once ITS loads are back (52 gate loads may still be in flight)
                     asm volatile("s_waitcnt vmcnt(52)" : "+v"(f0), "+v"(f1) : : "memory");
@@ -215,8 +236,23 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                 for (int k = 0; k < 26; ++k) {
                     if (k) asm volatile("" : "+v"(w[k][0]), "+v"(w[k][1]));
                     const v4f zero = {0.f, 0.f, 0.f, 0.f};
-                    w[k][0] = in0 ? w[k][0] : zero;
-                    w[k][1] = in1 ? w[k][1] : zero;
+                    if (ADJ) {
+                        const int c27 = k < 13 ? k : k + 1, dz = 1 - c27 / 9, dy = 1 - (c27 / 3) % 3, dx = 1 - c27 % 3;
+                        const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
+                        v4f q0 = in0 && rowok ? w[k][0] : zero, q1 = in1 && rowok ? w[k][1] : zero;
+                        if (dx < 0) {   // element 0 is the voxel left of the volume
+                            if (x == 0) q0 = v4f{0.f, q0.x, q0.y, q0.z};
+                            if (x + 4 == 0) q1 = v4f{0.f, q1.x, q1.y, q1.z};
+                        } else if (dx > 0) {   // element 3 is the voxel right of the volume
+                            if (x + 4 == g.W) q0 = v4f{q0.y, q0.z, q0.w, 0.f};
+                            if (x + 8 == g.W) q1 = v4f{q1.y, q1.z, q1.w, 0.f};
+                        }
+                        w[k][0] = q0;
+                        w[k][1] = q1;
+                    } else {
+                        w[k][0] = in0 ? w[k][0] : zero;
+                        w[k][1] = in1 ? w[k][1] : zero;
+                    }
                 }
                 P3_CHUNK(1);
                 __syncthreads();
@@ -270,6 +306,11 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
+                    if (levels) {   // the level history of the backward: owned voxels only
+                        float* lv = levels + (size_t)(g.lv0 + it * g.lvs) * total + vox;
+                        if (in0 && x >= ox0 && x < ox1) *reinterpret_cast<float4*>(lv) = r0;
+                        if (in1 && x + 4 >= ox0 && x + 4 < ox1) *reinterpret_cast<float4*>(lv + 4) = r1;
+                    }
                     P3_STAMP(1);
                     // TAGGED: publications are numbered through the whole launch and alternate between the two buffers, so the
                     // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
@@ -489,9 +530,12 @@ size_t persistent3d_workspace(int B, int D, int H, int W) {
     return 2 * (size_t)B * D * H * W * sizeof(float) + XBYTES + 4096 * sizeof(unsigned);
 }
 
-int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
-                         hipStream_t st) {
-    const Geo3 g = make_geo3(B, D, H, W, n_iter);
+// adjoint: the transposed operator (backward); levels: volume lv0 + it * lvs receives the result of step it < n_iter
+int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
+                     int H, int W, int n_iter, void* ws, hipStream_t st) {
+    Geo3 g = make_geo3(B, D, H, W, n_iter);
+    g.lv0 = lv0;
+    g.lvs = lvs;
     const size_t total = (size_t)B * D * H * W;
     float* scratch = (float*)ws;
     unsigned* sync = (unsigned*)((char*)(scratch + 2 * total) + XBYTES);
@@ -499,11 +543,18 @@ int persistent3d_forward(const float* gate, const float* feat, float* out, int B
     // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
     hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    if (flags_mode)
-        hipLaunchKernelGGL(cspn3d_persistent_kernel<false>, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
+    if (adjoint)
+        hipLaunchKernelGGL((cspn3d_persistent_kernel<true, true>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
+    else if (flags_mode && !levels)
+        hipLaunchKernelGGL((cspn3d_persistent_kernel<false, false>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
     else
-        hipLaunchKernelGGL(cspn3d_persistent_kernel<true>, dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, scratch, sync, g);
+        hipLaunchKernelGGL((cspn3d_persistent_kernel<true, false>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
     return check_launch("cspn3d_persistent_kernel");
+}
+
+int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
+                         hipStream_t st) {
+    return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st);
 }
 
 // test hook: the error word of the last run in this workspace (0 ok, 1 barrier timeout, 2 neighbour-flag timeout); syncs
