@@ -202,6 +202,15 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
                     "whole_forward_frac": round(fwd_frac, 4),
                     "note": "per launch = one propagation step (112 B/voxel); whole_forward_frac prices all %d iterations "
                             "against a single pass over the inputs" % n_iter}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc)).get("vol3d_B%d_%s" % (B, "persistent" if persistent else "stepwise"))
+                if t:
+                    roof["traffic"] = t["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = t.get("source")
+            except Exception:
+                pass
         res = {
             "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
             "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
