@@ -543,12 +543,17 @@ int persistent3d_run(const float* gate, const float* feat, float* out, float* le
     // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
     hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    if (adjoint)
-        hipLaunchKernelGGL((cspn3d_persistent_kernel<true, true>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
-    else if (flags_mode && !levels)
-        hipLaunchKernelGGL((cspn3d_persistent_kernel<false, false>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
-    else
-        hipLaunchKernelGGL((cspn3d_persistent_kernel<true, false>), dim3(g.n_wg), dim3(NTP), 0, st, gate, feat, out, levels, scratch, sync, g);
+    // Every workgroup waits for its neighbours' publications, so all of them must be resident at once: a cooperative launch
+    // makes the runtime check that and keeps two such kernels (other streams of this process) from being interleaved on
+    // the device, where each would hold the CUs the other is waiting for.
+    void* args[] = {(void*)&gate, (void*)&feat, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
+    const void* fn = adjoint ? (const void*)cspn3d_persistent_kernel<true, true>
+                             : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false>
+                                                      : (const void*)cspn3d_persistent_kernel<true, false>);
+    // (costs ~23 us per launch against a plain launch, 0.905 -> 0.928 ms at config 5; CSPN_3D_PLAIN_LAUNCH=1 for the A/B)
+    static const bool plain = getenv("CSPN_3D_PLAIN_LAUNCH") != nullptr;
+    e = plain ? hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st) : hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+    if (e != hipSuccess) { set_error("hipLaunchCooperativeKernel(cspn3d_persistent_kernel): %s", hipGetErrorString(e)); return (int)e; }
     return check_launch("cspn3d_persistent_kernel");
 }
 

@@ -414,3 +414,28 @@ def test_asm_paths_are_deterministic():
         if i % 4 == 0:
             gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
             assert torch.equal(gg, gg0) and torch.equal(gh, gh0)
+
+
+@pytest.mark.gpu
+def test_3d_persistent_kernels_on_two_streams_do_not_starve_each_other():
+    """two persistent forwards submitted to two streams at once: each needs all its workgroups resident, so they must not be
+    interleaved on the device (cooperative launch); both results are the per-step kernel's, and no poll timed out"""
+    B, D, H, W, N = 2, 32, 160, 304, 6
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device="cuda"); g /= g.sum(1, keepdim=True)
+    h1 = torch.rand(B, 1, D, H, W, generator=gen, device="cuda")
+    h2 = torch.rand(B, 1, D, H, W, generator=gen, device="cuda")
+    r1 = cspn_amd.cspn3d_forward(g, h1, None, N, "none", algo="stepwise")
+    r2 = cspn_amd.cspn3d_forward(g, h2, None, N, "none", algo="stepwise")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            o1, w1 = cspn_amd.cspn3d_forward(g, h1, None, N, "none", algo="persistent", _return_ws=True)
+        with torch.cuda.stream(s2):
+            o2, w2 = cspn_amd.cspn3d_forward(g, h2, None, N, "none", algo="persistent", _return_ws=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, r1) and torch.equal(o2, r2)
+        lib = cspn_amd.load()
+        assert lib.cspn_debug_3d_persistent_error(w1.data_ptr(), B, D, H, W) == 0
+        assert lib.cspn_debug_3d_persistent_error(w2.data_ptr(), B, D, H, W) == 0
