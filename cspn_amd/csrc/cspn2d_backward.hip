@@ -177,6 +177,16 @@ __device__ __forceinline__ float4 ld4u(const float* p) {   // 16 bytes, 4-byte a
 }
 __device__ __forceinline__ void st4u(float* p, float4 v) { __builtin_memcpy(p, &v, 16); }
 
+__device__ __forceinline__ float dpp_wshr1(float v) {   // across the wave: lane i <- lane i-1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float dpp_wshl1(float v) {   // across the wave: lane i <- lane i+1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+
+// RL = lanes per image row inside a wave: 16 (a wave = 4 rows x 16 groups, a block = 16 rows x 64 columns) or 64 (a wave = one
+// row of 64 groups = 1 KB per load, a block = 4 rows x 256 columns, blocks numbered so that vertical neighbours share an XCD)
+template <int RL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
                                                           const float* __restrict__ sparse, const float* __restrict__ hh,
                                                           const float* __restrict__ ah, const float* __restrict__ a0p,
@@ -188,10 +198,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     // a block = 16 rows x 16 groups (64 columns): a wave holds 4 rows of 16 groups, so the rows above / below a thread's row are
     // read by the same CU (L1) instead of by another XCD, and the columns beside a group come from the neighbouring lane of
     // the 16-lane DPP row
-    const int lane = threadIdx.x & 63, gx = lane & 15;
-    const int b = blockIdx.z;
-    const int y = blockIdx.y * 16 + ((threadIdx.x >> 6) << 2) + (lane >> 4);
-    const int xg = blockIdx.x * 16 + gx;
+    const int lane = threadIdx.x & 63, gx = lane & (RL - 1);
+    int b, y, xg;
+    if (RL == 16) {
+        b = blockIdx.z;
+        y = blockIdx.y * 16 + ((threadIdx.x >> 6) << 2) + (lane >> 4);
+        xg = blockIdx.x * 16 + gx;
+    } else {
+        // 1-D grid; hardware deals block i to XCD i % 8: give every XCD a contiguous run of tiles, numbered rows-first inside a
+        // (image, column-of-blocks) strip, so that the blocks above / below a block run on the same XCD at about the same time
+        const int nbx = (W4 + 63) / 64, nby = (H + 3) / 4, ntile = nbx * nby * B, per = (ntile + 7) / 8;
+        const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        const bool live = t < ntile && (int)(blockIdx.x >> 3) < per;
+        const int tt = live ? t : 0;
+        const int by = tt % nby, r = tt / nby, bx = r % nbx;
+        b = r / nbx;
+        y = live ? by * 4 + (int)(threadIdx.x >> 6) : H;
+        xg = bx * 64 + gx;
+    }
     const bool valid = y < H && xg < W4;
     const int x = 4 * (valid ? xg : 0);
     const size_t base = (size_t)b * HW, idx = base + (size_t)(valid ? y : 0) * W + x;
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
             if (rowin) L.r[d] = *reinterpret_cast<const float4*>(row + x);
             // c3 of the group to the left sits at position 1 of a register-order group, c0 of the group to the right at position 0
             if (gx == 0 && rowin && x > 0) L.e0[d] = row[h_reg_order ? x - 4 + 1 : x - 1];
-            if (gx == 15 && rowin && x + 4 < W) L.e5[d] = row[x + 4];
+            if (gx == RL - 1 && rowin && x + 4 < W) L.e5[d] = row[x + 4];
         }
     };
     auto compute = [&](const Lvl& L, bool first, bool last) {
@@ -240,10 +264,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
             else { h[1] = q.x; h[2] = q.z; h[3] = q.w; h[4] = q.y; }
             // the columns beside the group belong to the neighbouring lanes (the next / previous group of the same row); the end
             // lanes of a 16-lane row have fetched theirs (0 outside the image)
-            h[0] = dpp_shr1(h[4]);
-            h[5] = dpp_shl1(h[1]);
+            h[0] = RL == 16 ? dpp_shr1(h[4]) : dpp_wshr1(h[4]);
+            h[5] = RL == 16 ? dpp_shl1(h[1]) : dpp_wshl1(h[1]);
             if (gx == 0) h[0] = L.e0[d];
-            if (gx == 15) h[5] = L.e5[d];
+            if (gx == RL - 1) h[5] = L.e5[d];
             if (x + 4 >= W) h[5] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -385,6 +409,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
 
 }  // namespace
 
+// final pass of the assembly-sweep backward; CSPN_BWD_FINAL_RL=64 selects the one-row-per-wave mapping (A/B)
+static void launch_final4(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* a0,
+                          const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
+    static const bool rl64 = [] { const char* e = getenv("CSPN_BWD_FINAL_RL"); return e && atoi(e) == 64; }();
+    if (rl64) {
+        const int nbx = (W / 4 + 63) / 64, nby = (H + 3) / 4, ntile = nbx * nby * B, per = (ntile + 7) / 8;
+        hipLaunchKernelGGL(bwd_final4_kernel<64>, dim3(per * 8), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm);
+    } else {
+        hipLaunchKernelGGL(bwd_final4_kernel<16>, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
+                           gout, gg, gb, B, H, W, norm);
+    }
+}
+
 constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
                                      // one row up and one pixel left of its first row)
 static bool asm_path(int B, int H, int W, int n_iter) {
@@ -421,8 +458,7 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
             hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
                                H, W, n_iter, norm);
         else
-            hipLaunchKernelGGL(bwd_final4_kernel, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah,
-                               a0, gout, gg, gb, B, H, W, norm);
+            launch_final4(g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm, st);
         return check_launch("bwd_final_kernel");
     }
     float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
@@ -469,8 +505,7 @@ int backward2d_history(const float* g, const float* blur, const float* sparse, c
     float* ah = (float*)ws;
     float* a0 = ah + 23 * total;
     if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-    hipLaunchKernelGGL(bwd_final4_kernel, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
-                       gout, gg, gb, B, H, W, norm);
+    launch_final4(g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm, st);
     return check_launch("bwd_final4_kernel");
 }
 
