@@ -36,6 +36,7 @@ struct Geo3 {
     int nchunk;              // chunks per volume
     int n_wg;                // workgroups launched (>= tz * ty * cx)
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
+    long long gps, gbs;      // gate plane / batch stride in floats: [B][26][V] as given (V, 26 V) or folded planes [26][B][V] (B V, V)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -73,6 +74,10 @@ constexpr int QROW = 24, NROWS = TZ * TY, NQA = NROWS * QROW, NQ = NQA + 2 * NRO
 // what a tile fetches per step: 36 halo rows (above / below / beside in y) of 24 quads, and the 200 voxels beside it in x
 constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL, NSLOT = (NIT + NTP - 1) / NTP;
 
+__device__ __forceinline__ unsigned lds_addr(const void* p) {   // byte address inside the workgroup's LDS
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) {   // uniform base + per-lane 32-bit offset
     v4f v;
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
@@ -84,11 +89,15 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // off_j (4-byte aligned 16-byte loads; a quad that sticks out of the volume by its first / last element is read aligned and
 // shifted in the registers).  levels != nullptr: every step but the last also stores its owned voxels (the level history
 // the gate gradient multiplies with).
-template <bool TAGGED, bool ADJ>
+// HASC: a constant term per voxel, H_{t+1} = c' + sum_k w'_k H_t(p + off_k): the folded form of the normalising / masked modes
+// (fold3d_kernel of cspn3d_stepwise.hip writes w' and c'); c' of the thread's eight voxels waits in LDS between the steps.
+template <bool TAGGED, bool ADJ, bool HASC>
 __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
-                                                                 float* __restrict__ out, float* __restrict__ levels,
-                                                                 float* __restrict__ scratch, unsigned* __restrict__ sync, Geo3 g) {
+                                                                 const float* __restrict__ cprime, float* __restrict__ out,
+                                                                 float* __restrict__ levels, float* __restrict__ scratch,
+                                                                 unsigned* __restrict__ sync, Geo3 g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * LTILE];
+    __shared__ __attribute__((aligned(16))) float4 s_c[HASC ? 2 * NTP : 1];   // c' of the thread's two quads, [quad][thread]
     __shared__ int s_bail;
     unsigned* flags = sync;                  // [MAX_WG] per-tile step flags
     unsigned* bar = sync + MAX_WG;           // [64 * 9] barrier counters (one cache line each)
@@ -164,15 +173,21 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     const unsigned so = ok ? (unsigned)((vz * g.H + vy) * g.W + vx) * 4u : 0u;
                     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(fs[j]) : "v"(so), "s"(fb) : "memory");
                 }
+                v4f cq0, cq1;
+                if (HASC) {
+                    const float* cb = cprime + (size_t)b * V;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq0) : "v"(voff0), "s"(cb) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq1) : "v"(voff1), "s"(cb) : "memory");
+                }
                 // ---- the 26 gates of the thread's eight voxels: read once, kept in registers for all steps
                 v4f w[26][2];
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
-                    const float* gk = gate + ((size_t)b * 26 + k) * V;
+                    const float* gk = gate + (size_t)b * g.gbs + (size_t)k * g.gps;
                     if (ADJ) {
                         const int c27 = k < 13 ? k : k + 1, dz = 1 - c27 / 9, dy = 1 - (c27 / 3) % 3, dx = 1 - c27 % 3;
                         const int ko = (26 - c27) < 13 ? (26 - c27) : (26 - c27) - 1;   // the plane of the opposite offset
-                        const float* gko = gate + ((size_t)b * 26 + ko) * V;
+                        const float* gko = gate + (size_t)b * g.gbs + (size_t)ko * g.gps;
                         const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
                         const int sh = ((dz * g.H + dy) * g.W) * 4;
                         // first / last element outside the volume: read the aligned quad, shift afterwards
@@ -200,6 +215,15 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                 }
                 {   // level 0 into both LDS buffers once ITS loads are back (52 gate loads may still be in flight)
                     asm volatile("s_waitcnt vmcnt(52)" : "+v"(f0), "+v"(f1) : : "memory");
+                    if (HASC) {   // (outside the volume c' = 0: such voxels keep the value 0)
+                        asm volatile("" : "+v"(cq0), "+v"(cq1));
+                        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+                        const v4f c0 = in0 ? cq0 : zero, c1 = in1 ? cq1 : zero;
+                        // (explicit 32-bit LDS addresses: with more than 64 KB of LDS the compiler's base + immediate-offset
+                        // addressing went wrong, profiles/r02_perf_notes.md)
+                        const unsigned ca = lds_addr(s_c) + (unsigned)tc * 16u;
+                        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%3" : : "v"(ca), "v"(c0), "v"(c1), "n"(NTP * 16) : "memory");
+                    }
 #pragma unroll
                     for (int j = 0; j < NSHT; ++j) asm volatile("" : "+v"(fs[j]));
                     int tid_ = tid;
@@ -267,6 +291,14 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     float* nxt = lds + (it & 1) * LTILE;
                     P3_STAMP(0);
                     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (HASC) {
+                        const unsigned ca = lds_addr(s_c) + (unsigned)tid_ * 16u;
+                        v4f c0, c1;
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(c0), "=&v"(c1) : "v"(ca), "n"(NTP * 16) : "memory");
+                        acc[0] = c0.x; acc[1] = c0.y; acc[2] = c0.z; acc[3] = c0.w;
+                        acc[4] = c1.x; acc[5] = c1.y; acc[6] = c1.z; acc[7] = c1.w;
+                    }
 #pragma unroll
                     for (int n = 0; n < 9; ++n) {   // the 9 neighbour rows (dz, dy); three x-taps each
                         const int dz = 1 - n / 3, dy = 1 - n % 3;
@@ -530,13 +562,16 @@ size_t persistent3d_workspace(int B, int D, int H, int W) {
     return 2 * (size_t)B * D * H * W * sizeof(float) + XBYTES + 4096 * sizeof(unsigned);
 }
 
-// adjoint: the transposed operator (backward); levels: volume lv0 + it * lvs receives the result of step it < n_iter
-int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
-                     int H, int W, int n_iter, void* ws, hipStream_t st) {
+// adjoint: the transposed operator (backward); levels: volume lv0 + it * lvs receives the result of step it < n_iter;
+// cprime != nullptr: gate holds the 26 folded planes [26][B][V] and cprime the constant term (normalising / masked modes)
+static int persistent3d_launch(const float* gate, const float* feat, const float* cprime, float* out, float* levels, int lv0, int lvs,
+                               bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st) {
     Geo3 g = make_geo3(B, D, H, W, n_iter);
     g.lv0 = lv0;
     g.lvs = lvs;
     const size_t total = (size_t)B * D * H * W;
+    g.gps = cprime ? (long long)total : (long long)(total / B);
+    g.gbs = cprime ? (long long)(total / B) : 26LL * (long long)(total / B);
     float* scratch = (float*)ws;
     unsigned* sync = (unsigned*)((char*)(scratch + 2 * total) + XBYTES);
     static const bool flags_mode = getenv("CSPN_3D_FLAGS") != nullptr;   // A/B switch: the flag-based exchange of the first version
@@ -546,15 +581,27 @@ int persistent3d_run(const float* gate, const float* feat, float* out, float* le
     // Every workgroup waits for its neighbours' publications, so all of them must be resident at once: a cooperative launch
     // makes the runtime check that and keeps two such kernels (other streams of this process) from being interleaved on
     // the device, where each would hold the CUs the other is waiting for.
-    void* args[] = {(void*)&gate, (void*)&feat, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
-    const void* fn = adjoint ? (const void*)cspn3d_persistent_kernel<true, true>
-                             : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false>
-                                                      : (const void*)cspn3d_persistent_kernel<true, false>);
+    void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
+    const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<true, false, true>
+                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, true, false>
+                             : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false, false>
+                                                      : (const void*)cspn3d_persistent_kernel<true, false, false>);
     // (costs ~23 us per launch against a plain launch, 0.905 -> 0.928 ms at config 5; CSPN_3D_PLAIN_LAUNCH=1 for the A/B)
     static const bool plain = getenv("CSPN_3D_PLAIN_LAUNCH") != nullptr;
     e = plain ? hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st) : hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
     if (e != hipSuccess) { set_error("hipLaunchCooperativeKernel(cspn3d_persistent_kernel): %s", hipGetErrorString(e)); return (int)e; }
     return check_launch("cspn3d_persistent_kernel");
+}
+
+int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
+                     int H, int W, int n_iter, void* ws, hipStream_t st) {
+    return persistent3d_launch(gate, feat, nullptr, out, levels, lv0, lvs, adjoint, B, D, H, W, n_iter, ws, st);
+}
+
+// H_{t+1} = c' + sum_k w'_k H_t(p + off_k) with the folded planes wf = [26 w'][c'] of fold3d_kernel
+int persistent3d_forward_folded(const float* wf, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
+                                hipStream_t st) {
+    return persistent3d_launch(wf, feat, wf + 26 * (size_t)B * D * H * W, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st);
 }
 
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,

@@ -149,7 +149,9 @@ static bool direct3d_ok(const float* g, const float* feat, const float* sparse, 
 
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter) {
     (void)n_iter;
-    return (27 + 2) * (size_t)B * D * H * W * sizeof(float);   // large enough for every mode (fold planes + ping-pong)
+    // large enough for every mode: the 27 fold planes + what the persistent kernel wants (two value volumes = the ping-pong of
+    // the per-step path, its exchange buffers)
+    return 27 * (size_t)B * D * H * W * sizeof(float) + persistent3d_workspace(B, D, H, W);
 }
 
 // what the chosen path really needs: the Paddle contract (gates used as given, no mask) keeps two value volumes (+ the sync
@@ -157,7 +159,7 @@ size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter) {
 size_t forward3d_workspace(int B, int D, int H, int W, int n_iter, int norm, bool has_sparse) {
     (void)n_iter;
     if (norm == CSPN_NORM_NONE && !has_sparse && (W % 4) == 0) return persistent3d_workspace(B, D, H, W);
-    return (27 + 2) * (size_t)B * D * H * W * sizeof(float);
+    return stepwise3d_workspace(B, D, H, W, n_iter);
 }
 
 // algo: 0 auto, 1 one launch per step, 2 persistent (gates resident across steps)
@@ -166,8 +168,8 @@ int stepwise3d_forward(const float* g, const float* feat, const float* sparse, f
     const size_t total = (size_t)B * D * H * W;
     float* wf = (float*)ws;
     const bool direct = direct3d_ok(g, feat, sparse, out, W, norm, ws);
-    if (algo == 2 && !(direct && persistent3d_supported(B, D, H, W, n_iter))) {
-        set_error("persistent 3D kernel does not take this call (needs norm NONE, no mask, W %% 4 == 0, 2 <= n_iter <= 60, a chunk per device)");
+    if (algo == 2 && direct && !persistent3d_supported(B, D, H, W, n_iter)) {
+        set_error("persistent 3D kernel does not take this call (needs W %% 4 == 0, 16-byte aligned tensors, 2 <= n_iter <= 60, a chunk per device)");
         return CSPN_E_UNSUPPORTED;
     }
     if (direct && algo != 1 && persistent3d_supported(B, D, H, W, n_iter))
@@ -187,6 +189,15 @@ int stepwise3d_forward(const float* g, const float* feat, const float* sparse, f
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(fold3d_kernel, dim3(blocks), dim3(256), 0, st, g, feat, sparse, wf, B, D, H, W, norm);
     if (int e = check_launch("fold3d_kernel")) return e;
+    // the normalising / masked modes fused: H_{t+1} = c' + sum_k w'_k H_t(p + off_k) with the folded planes resident in the
+    // persistent kernel's registers (c' in LDS): fold once, then one pass over the 27 planes for all steps
+    const bool aligned = ((((uintptr_t)feat | (uintptr_t)out | (uintptr_t)ws) & 15u) == 0) && (W % 4) == 0 && (total % 4) == 0;
+    if (algo == 2 && !(aligned && persistent3d_supported(B, D, H, W, n_iter))) {
+        set_error("persistent 3D kernel does not take this call (needs W %% 4 == 0, 16-byte aligned tensors, 2 <= n_iter <= 60, a chunk per device)");
+        return CSPN_E_UNSUPPORTED;
+    }
+    if (algo != 1 && aligned && persistent3d_supported(B, D, H, W, n_iter))
+        return persistent3d_forward_folded(wf, feat, out, B, D, H, W, n_iter, wf + 27 * total, st);
     const float* src = feat;
     for (int it = 0; it < n_iter; ++it) {
         float* dst = (it == n_iter - 1) ? out : ping[it & 1];

@@ -38,6 +38,9 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter);
 size_t persistent3d_workspace(int B, int D, int H, int W);
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                          hipStream_t st);
+// the folded form of the normalising / masked modes: wf = 26 planes w' + the constant term c' ([27][B*V], fold3d_kernel)
+int persistent3d_forward_folded(const float* wf, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
+                                hipStream_t st);
 // the same run for the backward: adjoint = transposed operator; levels + (lv0 + it * lvs) volumes receive step it < n_iter
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
                      int H, int W, int n_iter, void* ws, hipStream_t st);

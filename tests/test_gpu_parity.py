@@ -417,6 +417,31 @@ def test_asm_paths_are_deterministic():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,D,H,W,N,norm,sp", [(1, 8, 8, 64, 3, "8sum_abs", False),      # one tile
+                                               (2, 20, 30, 200, 12, "8sum", True),       # several tiles and chunks, signed gates, mask
+                                               (1, 9, 17, 72, 5, "none", True),          # partial tiles, Paddle gates + mask
+                                               (1, 32, 160, 304, 6, "8sum_abs", True)])  # half of config 5's volume
+def test_3d_folded_modes_fused_vs_stepwise_and_oracle(B, D, H, W, N, norm, sp):
+    """the normalising / masked 3D modes: fold once, then all steps in the persistent kernel (folded planes in registers, the
+    constant term in LDS) -- bit-identical to fold + one launch per step, and equal to the oracle where it finishes in time"""
+    gen = torch.Generator(device="cuda").manual_seed(D * 10 + N)
+    g = torch.randn(B, 26, D, H, W, generator=gen, device="cuda") if norm == "8sum" else torch.rand(B, 26, D, H, W, generator=gen, device="cuda")
+    if norm == "none":
+        g = g / g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device="cuda")
+    s = (torch.rand(B, 1, D, H, W, generator=gen, device="cuda") < 0.05).float() * (h + 0.1) if sp else None
+    a, ws = cspn_amd.cspn3d_forward(g, h, s, N, norm, algo="persistent", _return_ws=True)
+    b = cspn_amd.cspn3d_forward(g, h, s, N, norm, algo="stepwise")
+    assert torch.equal(a, b)
+    assert torch.equal(a, cspn_amd.cspn3d_forward(g, h, s, N, norm))   # auto takes the fused path
+    if s is not None:
+        m = s != 0
+        assert torch.equal(a[m], h[m])   # pinned voxels keep their input value
+    if B * D * H * W <= 300000:
+        assert_close(a.cpu().numpy(), cspn3d_oracle(g.cpu(), h.cpu(), None if s is None else s.cpu(), N, norm), "3d folded fused")
+
+
+@pytest.mark.gpu
 def test_3d_persistent_kernels_on_two_streams_do_not_starve_each_other():
     """two persistent forwards submitted to two streams at once: each needs all its workgroups resident, so they must not be
     interleaved on the device (cooperative launch); both results are the per-step kernel's, and no poll timed out"""
