@@ -587,7 +587,12 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
                              : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false, false>
                                                       : (const void*)cspn3d_persistent_kernel<true, false, false>);
     // (costs ~23 us per launch against a plain launch, 0.905 -> 0.928 ms at config 5; CSPN_3D_PLAIN_LAUNCH=1 for the A/B)
-    static const bool plain = getenv("CSPN_3D_PLAIN_LAUNCH") != nullptr;
+    static const bool plain_env = getenv("CSPN_3D_PLAIN_LAUNCH") != nullptr;
+    // a stream that is being captured into a graph cannot take a cooperative launch: plain launch there (the replaying graph
+    // is the only thing on its stream; co-residency is the caller's business, as for any captured work)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    const bool plain = plain_env || capturing;
     e = plain ? hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st) : hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
     if (e != hipSuccess) { set_error("hipLaunchCooperativeKernel(cspn3d_persistent_kernel): %s", hipGetErrorString(e)); return (int)e; }
     return check_launch("cspn3d_persistent_kernel");

@@ -464,3 +464,28 @@ def test_3d_persistent_kernels_on_two_streams_do_not_starve_each_other():
         lib = cspn_amd.load()
         assert lib.cspn_debug_3d_persistent_error(w1.data_ptr(), B, D, H, W) == 0
         assert lib.cspn_debug_3d_persistent_error(w2.data_ptr(), B, D, H, W) == 0
+
+
+@pytest.mark.gpu
+def test_forward_paths_can_be_captured_in_a_graph():
+    """serving loops replay the propagation from a HIP graph: the 2D ring kernel and the 3D persistent kernel (plain launch while
+    the stream is capturing) are captured and replayed with new input values, results equal to the eager calls"""
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    g = torch.randn(2, 8, 96, 512, generator=gen, device="cuda")
+    h = torch.rand(2, 1, 96, 512, generator=gen, device="cuda") * 10
+    g3 = torch.rand(1, 26, 16, 24, 128, generator=gen, device="cuda"); g3 /= g3.sum(1, keepdim=True)
+    h3 = torch.rand(1, 1, 16, 24, 128, generator=gen, device="cuda")
+    cspn_amd.cspn2d_forward(g, h, None, 24, "8sum"); cspn_amd.cspn3d_forward(g3, h3, None, 6, "none")   # warm the allocator
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o2 = cspn_amd.cspn2d_forward(g, h, None, 24, "8sum")
+        o3 = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="persistent")
+    for seed in (1, 2):
+        gen2 = torch.Generator(device="cuda").manual_seed(seed)
+        h.copy_(torch.rand(2, 1, 96, 512, generator=gen2, device="cuda") * 10)
+        h3.copy_(torch.rand(1, 1, 16, 24, 128, generator=gen2, device="cuda"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o2, cspn_amd.cspn2d_forward(g, h, None, 24, "8sum"))
+        assert torch.equal(o3, cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="stepwise"))
