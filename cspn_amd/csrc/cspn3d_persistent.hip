@@ -22,12 +22,19 @@
 namespace cspn {
 namespace {
 
-constexpr int TZ = 8, TY = 8, TX = 64;          // tile = 4096 voxels, 8 consecutive x per thread
-constexpr int NTP = 512;                          // 2 waves per SIMD: 256 registers per thread, 208 of them gates
-constexpr int LZ = TZ + 2, LY = TY + 2, LXU = TX + 2, LX = 68;   // LDS tile with halo, rows padded to 68 floats
-constexpr int LTILE = LZ * LY * LX;              // 6800 floats per level buffer
+// XG = threads (groups of 8 consecutive x) per tile row.  8: one workgroup of 512 threads per CU, tile 8 x 8 x 64.  4 (-DP3_XG=4):
+// two workgroups of 256 threads per CU, tile 8 x 8 x 32 -- one's exchange round trip under the other's arithmetic.
+#ifndef P3_XG
+#define P3_XG 8
+#endif
+constexpr int XG = P3_XG, XGS = XG == 8 ? 3 : 2, WG_PER_CU = 8 / XG;
+static_assert(XG == 8 || XG == 4, "x-groups per tile row");
+constexpr int TZ = 8, TY = 8, TX = 8 * XG;       // 8 consecutive x per thread
+constexpr int NTP = 64 * XG;                      // 256 registers per thread, 208 of them gates
+constexpr int LZ = TZ + 2, LY = TY + 2, LXU = TX + 2, LX = TX + 4;   // LDS tile with halo, rows padded to a multiple of 4 floats
+constexpr int LTILE = LZ * LY * LX;              // floats per level buffer
 constexpr unsigned SPIN_MAX = 1u << 18;
-constexpr int MAX_WG = 256;
+constexpr int MAX_WG = 256 * WG_PER_CU;
 
 struct Geo3 {
     int B, D, H, W, n_iter, halo;
@@ -70,7 +77,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned epoch, int 
 // of row (lz, ly) owns the quads q3 = 0, 1, 2 of its values (0,1,2) (3,4,5) (6,7), stored at [q3][row][xg] so that a wave's store (and
 // a reader's load) covers whole 128-byte lines; written for boundary rows only.  The x faces (value 0 of xg = 0, value 7 of xg = 7)
 // of ALL rows follow at [side][row], one value per quad.
-constexpr int QROW = 24, NROWS = TZ * TY, NQA = NROWS * QROW, NQ = NQA + 2 * NROWS;   // 1536 + 128 quads per tile and level parity
+constexpr int QROW = 3 * XG, NROWS = TZ * TY, NQA = NROWS * QROW, NQ = NQA + 2 * NROWS;   // 1536 + 128 quads per tile and level parity
 // what a tile fetches per step: 36 halo rows (above / below / beside in y) of 24 quads, and the 200 voxels beside it in x
 constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL, NSLOT = (NIT + NTP - 1) / NTP;
 
@@ -92,7 +99,7 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // HASC: a constant term per voxel, H_{t+1} = c' + sum_k w'_k H_t(p + off_k): the folded form of the normalising / masked modes
 // (fold3d_kernel of cspn3d_stepwise.hip writes w' and c'); c' of the thread's eight voxels waits in LDS between the steps.
 template <bool TAGGED, bool ADJ, bool HASC>
-__global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
+__global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
                                                                  const float* __restrict__ cprime, float* __restrict__ out,
                                                                  float* __restrict__ levels, float* __restrict__ scratch,
                                                                  unsigned* __restrict__ sync, Geo3 g) {
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                 constexpr int NSHT = (NSH + NTP - 1) / NTP;
                 int tc = tid;   // opaque per chunk: nothing below may be hoisted out of the chunk loop (it would be spilled, and a
                 asm volatile("" : "+v"(tc));   // spill reload waits for every load in flight)
-                const int lx = (tc & 7) * 8, ly = (tc >> 3) & 7, lz = tc >> 6;
+                const int lx = (tc & (XG - 1)) * 8, ly = (tc >> XGS) & 7, lz = tc >> (XGS + 3);
                 const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
                 const bool in_zy = z < g.D && y < g.H;
                 const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
 #elif defined(P3_EXP_LANE_REMAP)   // WRONG RESULTS: each instruction reads 128 contiguous bytes per row
-                    const int xa = x0 + (tc & 7) * 4;
+                    const int xa = x0 + (tc & (XG - 1)) * 4;
                     const unsigned ra = (unsigned)((z * g.H + y) * g.W + xa) * 4u;
                     const unsigned r0_ = (in_zy && xa >= 0 && xa + 3 < g.W) ? ra : 0u, r1_ = (in_zy && xa + 32 >= 0 && xa + 35 < g.W) ? ra + 128u : 0u;
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(r0_), "s"(gk) : "memory");
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     for (int j = 0; j < NSHT; ++j) asm volatile("" : "+v"(fs[j]));
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
-                    const int lx = (tid_ & 7) * 8, ly = (tid_ >> 3) & 7, lz = tid_ >> 6;
+                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
                     const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
                     const bool in_zy = z < g.D && y < g.H;
                     const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                     // tid_ each step (a handful of integer instructions) instead of being kept live across the loop
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
-                    const int lx = (tid_ & 7) * 8, ly = (tid_ >> 3) & 7, lz = tid_ >> 6;
+                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
                     const float* cur = lds + ((it - 1) & 1) * LTILE;
                     float* nxt = lds + (it & 1) * LTILE;
                     P3_STAMP(0);
@@ -354,12 +361,12 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                         // boundary rows publish all 24, the others only the first and the last (the x faces).
                         {
                             float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
-                            float4* rowq = mine + (lz * TY + ly) * 8 + (lx >> 3);
+                            float4* rowq = mine + (lz * TY + ly) * XG + (lx >> 3);
                             const float tagf = __uint_as_float(target);
                             if (lz == 0 || lz == TZ - 1 || ly == 0 || ly == TY - 1) {
                                 st16_sc1(reinterpret_cast<float*>(rowq), make_float4(acc[0], acc[1], acc[2], tagf));
-                                st16_sc1(reinterpret_cast<float*>(rowq + NROWS * 8), make_float4(acc[3], acc[4], acc[5], tagf));
-                                st16_sc1(reinterpret_cast<float*>(rowq + 2 * NROWS * 8), make_float4(acc[6], acc[7], 0.f, tagf));
+                                st16_sc1(reinterpret_cast<float*>(rowq + NROWS * XG), make_float4(acc[3], acc[4], acc[5], tagf));
+                                st16_sc1(reinterpret_cast<float*>(rowq + 2 * NROWS * XG), make_float4(acc[6], acc[7], 0.f, tagf));
                             }
                             if (lx == 0) st16_sc1(reinterpret_cast<float*>(mine + NQA + lz * TY + ly), make_float4(acc[0], 0.f, 0.f, tagf));
                             if (lx == TX - 8) st16_sc1(reinterpret_cast<float*>(mine + NQA + NROWS + lz * TY + ly), make_float4(acc[7], 0.f, 0.f, tagf));
@@ -381,8 +388,8 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                                 const int hr = item / QROW, quad = item - hr * QROW;
                                 if (hr < 2 * LY) { pz = hr < LY ? 0 : LZ - 1; py = hr < LY ? hr : hr - LY; }
                                 else { const int u = hr - 2 * LY; py = u < TZ ? 0 : LY - 1; pz = 1 + (u < TZ ? u : u - TZ); }
-                                q3 = quad >> 3;
-                                xg = quad & 7;
+                                q3 = quad >> XGS;
+                                xg = quad & (XG - 1);
                                 px = 1 + 8 * xg + 3 * q3;
                                 cnt = q3 == 2 ? 2 : 3;
                             } else {
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(NTP) void cspn3d_persistent_kernel(const float* __r
                             // the row inside the neighbour tile
                             const int sz = pz == 0 ? TZ - 1 : (pz == LZ - 1 ? 0 : pz - 1), sy = py == 0 ? TY - 1 : (py == LY - 1 ? 0 : py - 1);
                             const int nbw = (tz2 * g.ty + ty2) * g.cx + tx2;
-                            const int quad = q3 >= 0 ? (q3 * NROWS + sz * TY + sy) * 8 + xg : NQA + xg * NROWS + sz * TY + sy;
+                            const int quad = q3 >= 0 ? (q3 * NROWS + sz * TY + sy) * XG + xg : NQA + xg * NROWS + sz * TY + sy;
                             src[j] = (unsigned)((((int)(target & 1) * g.n_wg + nbw) * NQ + quad) * 16);
                             dstp[j] = ((pz * LY + py) * LX + px) | (cnt << 14);
                         }
@@ -526,6 +533,7 @@ int resident_wgs() {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess) return MAX_WG;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return MAX_WG;
+        v *= WG_PER_CU;
         return v < MAX_WG ? v : MAX_WG;
     }();
     return n;
