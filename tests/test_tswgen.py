@@ -156,3 +156,13 @@ def test_scheduler_respects_hazards_and_emulator_flags_misuse():
         else:
             with pytest.raises(EmuError, match="race"):
                 e.run()
+
+
+@pytest.mark.parametrize("sched_seed", [None, 7])
+def test_emulated_elastic_loop_vs_oracle(sched_seed):
+    """cfg elastic (no barrier in the loop: boundary rows and ring slots are validated by tags, profiles/r02_perf_notes.md)
+    under the emulator's most skewed schedule and under a random one with stalls"""
+    os.chdir(ROOT)
+    err, nanmis, out, ref = run_case(2, 17, 304, 5, 0, True, False, seed=5, zero_patch=True, verbose=False, elastic=True,
+                                     sched_seed=sched_seed)
+    assert nanmis == 0 and err <= 1e-4 and np.isnan(ref).any()

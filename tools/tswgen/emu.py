@@ -58,6 +58,7 @@ class Emu(object):
         self.waves = [Wave(w) for w in range(nwaves)]
         self.nsteps = 0
         self.check_races = True
+        self.sched_rng = None
 
     # ---- operand access -----------------------------------------------------------------------------
     def _chk(self, w, reg):
@@ -206,6 +207,8 @@ class Emu(object):
             w.done = True
         elif o == "s_barrier":
             w.at_barrier = True
+        elif o == "s_sleep":   # elastic kernels poll LDS tags: give the other waves a turn
+            w.yielded = True
         elif o == "s_waitcnt":
             if "vmcnt" in m:
                 while len(w.vm_q) > m["vmcnt"]:
@@ -426,7 +429,7 @@ class Emu(object):
                     a, b = rvf(w, s[0]), rvf(w, s[1])
                 else:
                     a, b = rv(w, s[0]).astype(np.int64), rv(w, s[1]).astype(np.int64)
-                r = {"eq": a == b, "gt": a > b, "ge": a >= b, "lt": a < b, "le": a <= b}[kind] & ex
+                r = {"eq": a == b, "ne": a != b, "gt": a > b, "ge": a >= b, "lt": a < b, "le": a <= b}[kind] & ex
                 self.ws64(w, d[0], int(_bool_to_mask(r)))
             elif o == "v_readfirstlane_b32":
                 lanes = np.nonzero(ex)[0]
@@ -491,8 +494,13 @@ class Emu(object):
         n = 0
         while True:
             progressed = False
-            for w in self.waves:
-                while not w.done and not w.at_barrier:
+            order = list(self.waves)
+            if self.sched_rng is not None:   # adversarial schedule for barrier-free kernels: random order, random stalls
+                self.sched_rng.shuffle(order)
+                order = [w for w in order if self.sched_rng.random() < 0.5] or order[:1]
+            for w in order:
+                w.yielded = False
+                while not w.done and not w.at_barrier and not w.yielded:
                     if w.pc >= len(self.ins):
                         w.done = True
                         break
@@ -510,7 +518,8 @@ class Emu(object):
                 for w in live:
                     w.at_barrier = False
                 self.epoch += 1
-            elif not progressed:
+            elif not progressed and self.sched_rng is None:
                 raise EmuError("deadlock")
+
         self.ninstr = n
         return n

@@ -79,7 +79,7 @@ VOP_PK = {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32"}
 VOP_TRANS = {"v_rcp_f32"}
 VOP_E32 = {"v_mov_b32", "v_rcp_f32", "v_lshlrev_b32", "v_lshrrev_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32",
            "v_mul_f32", "v_add_f32", "v_sub_f32", "v_mul_u32_u24", "v_xor_b32"}
-VOP_E64 = {"v_fma_f32", "v_cndmask_b32", "v_cmp_ge_u32", "v_cmp_lt_u32", "v_cmp_gt_f32", "v_cmp_lt_f32", "v_cmp_eq_u32",
+VOP_E64 = {"v_fma_f32", "v_cndmask_b32", "v_cmp_ge_u32", "v_cmp_lt_u32", "v_cmp_gt_f32", "v_cmp_lt_f32", "v_cmp_eq_u32", "v_cmp_ne_u32",
            "v_mad_u32_u24"}
 DS_OPS = {"ds_read_b128", "ds_write_b128", "ds_write2_b32", "ds_read_b64", "ds_write_b64", "ds_write_b32", "ds_read_b32",
           "ds_read2st64_b32", "ds_write2st64_b32", "ds_read2_b32"}
@@ -111,7 +111,7 @@ class I(object):
         o = self.op
         if o == "pseudo":
             return False
-        return (o in BRANCH or o in ("label", "s_waitcnt", "s_barrier", "s_nop", "s_endpgm", "raw") or
+        return (o in BRANCH or o in ("label", "s_waitcnt", "s_barrier", "s_nop", "s_sleep", "s_endpgm", "raw") or
                 o == "s_and_saveexec_b64" or any(isinstance(d, R) and d.kind == "exec" for d in self.dst))
 
     def is_mem(self):
@@ -169,8 +169,8 @@ class I(object):
             return "s_waitcnt " + " ".join(parts)
         if o in ("s_barrier", "s_endpgm"):
             return o
-        if o == "s_nop":
-            return "s_nop %d" % s[0]
+        if o in ("s_nop", "s_sleep"):
+            return "%s %d" % (o, s[0])
         if o in BRANCH:
             return "%s %s" % (o, s[0])
         if o in DS_OPS:

@@ -21,8 +21,13 @@ DESC_BYTES = 16              # goff_lo, goff_hi, boff, flags | lo << 8 | hi << 2
 # cooking lanes (two per record, 8 adjacent bytes each) and the reading lanes (stride 42 dwords) are free of bank conflicts
 RING_REC = 168
 LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 64 * RING_REC
-LDS_TAB = LDS_RING + 8 * RING_SLOT   # the workgroup's row-descriptor table (written by the C++ part of the kernel)
-TAB_MAX_ROWS = 2816
+# cfg elastic: no barrier in the loop -- a wave tells its ring neighbours with a tag that the boundary rows of a step are in LDS
+# (mailbox of the READER: [8 waves][2 counter parities][top, bottom] dwords), and the cooking waves tag the ring slots
+# ([8 slots][2 halves] dwords, at TAG_RT).  Inside the range the C++ preamble zero-fills: tag 0 is never expected.
+LDS_TAGS = LDS_RING + 8 * RING_SLOT
+TAG_RT = 128
+LDS_TAB = LDS_TAGS + 256             # the workgroup's row-descriptor table (written by the C++ part of the kernel)
+TAB_MAX_ROWS = 2800
 LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES   # 160 KB
 assert LDS_BYTES <= 163840
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
@@ -86,6 +91,11 @@ S_WF = S(50, 2)     # history mode: the 8 folded coefficient planes w'_k ([8][B*
 S_PBOFF = S(47)     # history mode: byte offset (1-channel tensor) of the pending task's row
 S_CMASK = S(52, 2)  # history mode: cooking lanes (2 pixels each) whose pixels lie in the band's owned columns
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
+# cfg elastic (never together with hist / hin / pf / trace, whose registers these are)
+S_MBR, S_TWU, S_TWD, S_RTW = [S(84), S(85)], [S(86), S(87)], [S(88), S(89)], [S(90), S(91)]   # LDS addresses, per counter parity
+S_RTR, S_EXP, S_EXR, S_SPIN, S_MB0, S_EXW = S(96), S(97), S(98), S(99), S(92), S(93)
+V_TGB, V_TGR = V(70, 2), V(74, 2)   # boundary tags (top, bottom) / ring tags (cooking half 0, 1); also the tag writers' temporaries
+SPIN_MAX = 1 << 16
 S_ELC, S_ERC = S(80, 2), S(82, 2)   # per-wave constant lane masks (half 0: lane 0 / half 1: lane 63)
 GB_MID, B_BLUR, B_HIN, B_SP = S(2, 2), S(6, 2), S(8, 2), S(10, 2)  # row bases of the requested task (s0:1, s4:5: S_HM)
 
@@ -112,6 +122,11 @@ class Gen(object):
         self.sited = (self.norm != 2 or self.adj) and not self.s8   # guidance plane k is read at (y + dy_k, x + dx_k)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
+        self.estubs = []
+        self.elastic = cfg.get("elastic", False)
+        if self.elastic:
+            assert not (self.hist or self.hin or cfg.get("pf") or cfg.get("trace") or cfg.get("cook_early") or cfg.get("spread3"))
+            assert cfg.get("tab_in_lds", True) and cfg.get("partial_wait", True) and cfg.get("slim_events", True)
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong): nocook noevents noact nobar nolds
 
     # ---------------------------------------------------------------------------------- small helpers
@@ -378,6 +393,8 @@ class Gen(object):
         hn, ha = (HN, HA) if (not slim or ev is None or ev % 2 == 0) else (HA, HN)
         # ---- top: everything that travels through LDS is requested first; what the chain needs at once comes first, because
         # the LDS operations of a wave complete in order and the waits below count the requests that may stay outstanding
+        if self.elastic:   # the tags first: LDS serves a wave's requests in order, a valid tag proves the data read behind it
+            self.tag_reads(c, p, ev)
         if "nolds" not in self.ab:
             self.e("ds_read_b128", BQ, [V_RB[p]], at=0.0)
             self.e("ds_read_b128", TQ, [V_RT[p]], at=0.0)
@@ -387,17 +404,7 @@ class Gen(object):
         if ev is not None:
             self.fetch_event(ev)
             n_after += 2
-            self.e("v_add_u32", V_RINGE[0], [ev * RING_SLOT, V_RINGR])
-            self.ring_read(hn, V_RINGE[0], 9, at=0.0)
-            n_after += 2
-            if ev > 0:
-                if not slim:
-                    self.e("v_add_u32", V_RINGE[1], [(ev - 1) * RING_SLOT, V_RINGR])
-                    self.ring_read(ha, V_RINGE[1], 9, at=0.0)
-                    n_after += 2
-                for k in self.early_planes(ev):
-                    self.ring_read(WT(ev, k), V_RINGE[0], k, at=0.0)
-                n_after += 2 * len(self.early_planes(ev))
+            n_after += self.top_ring_reads(ev, hn, ha, slim)
             if "noevlds" in self.ab:
                 n_after = 2
         loads, deferred = [], []
@@ -416,6 +423,8 @@ class Gen(object):
                 n_after += 2 * len(self.early_planes(0))
         self.p.waitcnt(lgkm=min(n_after, 15) if partial else 0)
         self.probe(2)
+        if self.elastic:
+            self.tag_check(c, p, ev, hn, ha, slim)
         if ev is not None and not partial:
             self.take_event()
         if cook:
@@ -423,6 +432,10 @@ class Gen(object):
             self.issue_prepare(S_CD)
             self.e("s_add_i32", S_PQ, [S_PQ, 4])
             self.ring_writes(deferred, self.cfg.get("rw_at", 0.02), self.cfg.get("rw_at", 0.02) + self.cfg.get("rw_span", 0.5))
+            if self.elastic:   # behind the ring writes (LDS keeps a wave's order): this half of the slot is cooked
+                self.mov(V_TGR[0], S_TAU)
+                self.mov(V_TGR[1], S_RTW[g])
+                self.e("ds_write_b32", (), [V_TGR[1], V_TGR[0]], at=0.6)
             loads = self.load_list()
             if self.cfg.get("spread3", False):   # a third of the requests now, the rest in the two following steps
                 loads = loads[0::3]
@@ -459,8 +472,15 @@ class Gen(object):
                 self.hist_store(j, vq)
             if j == 3 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024, at=0.0)
+                if self.elastic:   # the wave below reads this row as its "top": its mailbox, entry 0
+                    self.mov(V_TGB[0], S_TAU)
+                    self.mov(V_TGB[1], S_TWU[p])
+                    self.e("ds_write_b32", (), [V_TGB[1], V_TGB[0]], at=0.0)
             if j == 0 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=0, at=0.0)
+                if self.elastic:   # the wave above reads this row as its "bottom": its mailbox, entry 1
+                    self.mov(V_TGB[1], S_TWD[p])
+                    self.e("ds_write_b32", (), [V_TGB[1], V_TGB[0]], at=0.0)
             if j == 0:
                 break  # slot 0's own pushes: tail(), at the top of the next step
             self.shift(vq, tq)
@@ -478,9 +498,10 @@ class Gen(object):
         self.probe(3)
         if prio:
             self.e("raw", (), ["s_setprio 0"])
-        self.p.waitcnt(lgkm=0)
+        if not self.elastic:
+            self.p.waitcnt(lgkm=0)
         self.probe(4)
-        if "nobar" not in self.ab:
+        if "nobar" not in self.ab and not self.elastic:
             self.e("s_barrier")
         self.probe(5)
         self.trace_flush(c, cook)
@@ -488,6 +509,95 @@ class Gen(object):
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
         if c == LV - 1:
             self.e("s_branch", (), [".LS0_%="])
+
+    # ---------------------------------------------------------------------------------- cfg elastic: tags instead of the barrier
+    def tag_reads(self, c, p, ev, stub=False):
+        m = {} if stub else {"at": 0.0}
+        self.mov(V_TGB[0], S_MBR[p])
+        self.e("ds_read_b64", V_TGB, [V_TGB[0]], **m)
+        if ev is not None:
+            self.mov(V_TGR[0], S_RTR)
+            self.e("ds_read_b64", V_TGR, [V_TGR[0]], offset=ev * 8, **m)
+        if c % 3 == 1:
+            # The step after next cooks group g + 2 into the ring slots of group g.  Their last reader is wave g at its counter 2
+            # (global step 3g + 2; this is 3g + 4): it must be through with that step.  Its progress is the tag it leaves in the
+            # mailbox of the wave above it (entry "bottom", counter parity 0) -- written after every ring read of the step.
+            k = (c - 4) // 3   # wave g = wv + k
+            self.e("s_add_i32", T[8], [S_WV, (k - 1) % 8])
+            self.e("s_and_b32", T[8], [T[8], 7])
+            self.e("s_lshl_b32", T[8], [T[8], 4])
+            self.e("s_add_i32", T[8], [T[8], S_MB0])
+            self.mov(V_DC[0], T[8])
+            self.e("ds_read_b32", V_DC[0], [V_DC[0]], offset=4, **m)
+
+    def tag_compare(self, c, ev):
+        """scc = 1 <=> a tag is not the expected one.  Boundary rows: written in the step before (S_TAU + 1); ring slot of
+        the event: rows entering at counter 0, 1, 2 were cooked in the step before counter 0, the one entering at 3 in
+        the step before (with the next wave's group)."""
+        a, b = S(T[4].i, 2), S(T[6].i, 2)
+        self.e("s_add_i32", S_EXP, [S_TAU, 1])
+        self.e("v_cmp_ne_u32", a, [V_TGB[0], S_EXP])
+        self.e("v_cmp_ne_u32", b, [V_TGB[1], S_EXP])
+        self.e("s_or_b64", a, [a, b])
+        if ev is not None:
+            self.e("s_add_i32", S_EXR, [S_TAU, 1 if ev == 3 else ev + 1])
+            for i in (0, 1):
+                self.e("v_cmp_ne_u32", b, [V_TGR[i], S_EXR])
+                self.e("s_or_b64", a, [a, b])
+        if c % 3 == 1:   # S_TAU counts down: "through with global step 3g + 2" = a tag <= S_TAU + 2
+            self.e("s_add_i32", S_EXW, [S_TAU, 2])
+            self.e("v_cmp_gt_u32", b, [V_DC[0], S_EXW])
+            self.e("s_or_b64", a, [a, b])
+        # (the last s_or_b64 left scc = (a != 0))
+
+    def top_ring_reads(self, ev, hn, ha, slim, stub=False):
+        """the ring requests an event step makes before its mid-step wait (shared by the step and its retry stub)"""
+        m = {} if stub else {"at": 0.0}
+        n = 0
+        self.e("v_add_u32", V_RINGE[0], [ev * RING_SLOT, V_RINGR])
+        self.ring_read(hn, V_RINGE[0], 9, **m)
+        n += 2
+        if ev > 0:
+            if not slim:
+                self.e("v_add_u32", V_RINGE[1], [(ev - 1) * RING_SLOT, V_RINGR])
+                self.ring_read(ha, V_RINGE[1], 9, **m)
+                n += 2
+            for k in self.early_planes(ev):
+                self.ring_read(WT(ev, k), V_RINGE[0], k, **m)
+            n += 2 * len(self.early_planes(ev))
+        return n
+
+    def tag_check(self, c, p, ev, hn, ha, slim):
+        stub, back = self.p.newlabel("tagw"), self.p.newlabel("tagb")
+        self.tag_compare(c, ev)
+        self.e("s_cbranch_scc1", (), [stub])
+        self.p.label(back)
+        self.estubs.append((stub, back, c, p, ev, hn, ha, slim))
+
+    def emit_tag_stub(self, stub, back, c, p, ev, hn, ha, slim):
+        """out of line: poll until the neighbours' (and the cooks') tags of this step are there, then repeat the requests the
+        step made at its top, whose answers may be stale"""
+        loop = self.p.newlabel("tagl")
+        self.p.label(stub)
+        self.e("s_mov_b32", S_SPIN, [0])
+        self.p.label(loop)
+        self.e("s_sleep", (), [1])
+        self.e("s_add_u32", S_SPIN, [S_SPIN, 1])
+        self.e("s_cmp_gt_u32", (), [S_SPIN, SPIN_MAX])
+        self.e("s_cbranch_scc1", (), [".Labort_%="])
+        self.tag_reads(c, p, ev, stub=True)
+        self.p.waitcnt(lgkm=0)
+        self.tag_compare(c, ev)
+        self.e("s_cbranch_scc1", (), [loop])
+        self.e("ds_read_b128", BQ, [V_RB[p]])
+        self.e("ds_read_b128", TQ, [V_RT[p]])
+        if ev is not None:
+            self.top_ring_reads(ev, hn, ha, slim, stub=True)
+            if ev == 0:
+                for k in self.early_planes(0):
+                    self.ring_read(WT(0, k), V_RINGE[0], k)
+        self.p.waitcnt(lgkm=0)
+        self.e("s_branch", (), [back])
 
     # ---------------------------------------------------------------------------------- cooking
     def cook_pending(self, ringw):
@@ -775,6 +885,46 @@ class Gen(object):
             e("s_lshl_b32", T[6], [T[6], 11])
             e("s_add_i32", T[7], [T[5], T[6]])
             e("v_add_u32", V_RB[p], [T[7], V_L16])
+        if self.elastic:
+            e("s_add_i32", T[8], [S_LDSB, LDS_TAGS])
+            e("s_mov_b32", S_MB0, [T[8]])
+            for p in (0, 1):
+                e("s_lshl_b32", T[9], [S_WV, 4])                 # own mailbox, counter parity p: [top, bottom]
+                e("s_add_i32", T[9], [T[9], T[8]])
+                e("s_add_i32", S_MBR[p], [T[9], p * 8])
+                for reg, dw, ent in ((S_TWU, 1, 0), (S_TWD, 7, 4)):   # the wave below reads my row as "top", the wave above as "bottom"
+                    e("s_add_i32", T[9], [S_WV, dw])
+                    e("s_and_b32", T[9], [T[9], 7])
+                    e("s_lshl_b32", T[9], [T[9], 4])
+                    e("s_add_i32", T[9], [T[9], T[8]])
+                    e("s_add_i32", reg[p], [T[9], p * 8 + ent])
+            e("s_add_i32", T[8], [T[8], TAG_RT])
+            e("s_lshl_b32", T[9], [T[1], 5])                     # the event side reads the four slots of the wave's half
+            e("s_add_i32", S_RTR, [T[8], T[9]])
+            for x in (0, 1):                                     # the cooking side: same slot arithmetic as V_RINGW[x]
+                e("s_xor_b32", T[9], [T[1], x])
+                e("s_lshl_b32", T[9], [T[9], 2])
+                e("s_add_i32", T[9], [T[9], T[2]])
+                e("s_add_i32", T[9], [T[9], 7])
+                e("s_and_b32", T[9], [T[9], 7])
+                e("s_lshl_b32", T[9], [T[9], 3])
+                e("s_add_i32", T[9], [T[9], T[8]])
+                e("s_lshl_b32", T[10], [T[1], 2])
+                e("s_add_i32", S_RTW[x], [T[9], T[10]])
+            # what the first step expects to find: "written in the step before" = S_LAST + 1, in the mailboxes of the two
+            # neighbours for the counter parity they start with ((wv + 1) & 1, the same for both)
+            # (the other parity's entries are written during step 0; until then they say "not yet" to everybody)
+            e("s_add_i32", T[10], [S_LAST, 1])
+            self.mov(V_TGB[0], T[10])
+            self.mov(V_TGR[0], 0x7fffffff)
+            e("s_cmp_eq_u32", (), [T[1], 0])
+            for reg in (S_TWU, S_TWD):
+                e("s_cselect_b32", T[9], [reg[1], reg[0]])
+                self.mov(V_TGB[1], T[9])
+                e("ds_write_b32", (), [V_TGB[1], V_TGB[0]])
+                e("s_cselect_b32", T[9], [reg[0], reg[1]])
+                self.mov(V_TGR[1], T[9])
+                e("ds_write_b32", (), [V_TGR[1], V_TGR[0]])
         # ring read base: LDS_RING + (wv&1)*4*RING_SLOT + lane*RING_REC
         e("s_mul_i32", T[3], [T[1], 4 * RING_SLOT])
         e("s_add_i32", T[3], [T[3], LDS_RING])
@@ -909,6 +1059,14 @@ class Gen(object):
             e("s_bitcmp1_b32", (), [S_WV, 2])
             e("s_cbranch_scc1", (), [l_late])
         self.ring_writes(self.cook_pending(V_TMP))
+        if self.elastic:   # task 0 counts as cooked in the step before the first one
+            e("s_add_i32", T[10], [S_LAST, 1])
+            self.mov(V_TGR[0], T[10])
+            e("s_and_b32", T[9], [S_WV, 1])
+            e("s_cmp_eq_u32", (), [T[9], 0])
+            e("s_cselect_b32", T[9], [S_RTW[0], S_RTW[1]])
+            self.mov(V_TGR[1], T[9])
+            e("ds_write_b32", (), [V_TGR[1], V_TGR[0]])
         self.p.waitcnt(lgkm=0)
         self.take_cook()
         self.issue_task(S_CD, first_third=self.cfg.get("spread3", False))   # the loop's first two steps request the rest
@@ -937,6 +1095,11 @@ class Gen(object):
             self.step(c)
         self.p.label(".Lexit_%=")
         self.e("s_branch", (), [".Lend_%="])
+        for st in self.estubs:
+            self.emit_tag_stub(*st)
+        if self.elastic:
+            self.p.label(".Labort_%=")   # a tag never came (cannot happen unless a wave died): leave instead of hanging
+            self.e("s_endpgm")
         for stub, back, vq, j in self.stubs:
             self.p.label(stub)
             self.e("s_bitcmp1_b32", (), [S_ACT, j])

@@ -11,7 +11,7 @@ from .plan import build_plan
 
 
 def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False,
-             s8=False):
+             s8=False, elastic=False, sched_seed=None):
     sys.path.insert(0, ".")
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
@@ -30,7 +30,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     hinv = None
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
-    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, s8=s8), sched=sched)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, s8=s8, elastic=elastic), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
@@ -59,6 +59,10 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         if hdr[wg, 0] == 0:
             continue
         emu = Emu(prog, mem, K.LDS_BYTES)
+        if elastic:   # no barrier epochs to check races in: the tags order the accesses (and the emulator runs every wave
+            emu.check_races = False   # until it has to wait for a tag; sched_seed: random order and random stalls on top)
+            if sched_seed is not None:
+                emu.sched_rng = np.random.default_rng(sched_seed + wg)
         fill_table(emu, tab[wg])
         for w in emu.waves:
             w.v[0] = np.arange(64, dtype=np.uint32)
