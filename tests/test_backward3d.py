@@ -75,7 +75,8 @@ def test_abi_exports_3d_backward_and_rejects_normalising_modes():
                                                (2, 6, 10, 37, 12, False),
                                                (1, 8, 8, 64, 3, True),       # fused sweeps, one tile
                                                (2, 20, 30, 200, 12, False),  # fused sweeps: several tiles and chunks per volume
-                                               (1, 9, 17, 72, 5, True)])     # fused sweeps, partial tiles, signed gates
+                                               (1, 9, 17, 72, 5, True),      # fused sweeps, partial tiles, signed gates
+                                               (1, 10, 9, 68, 4, True)])     # fused sweeps, W % 8 == 4: the volume ends inside a thread's first quad
 def test_hip_3d_backward_vs_oracle(B, D, H, W, N, signed):
     import cspn_amd
     g, h, go = _inputs(B, D, H, W, seed=11 + N, signed=signed)

@@ -264,7 +264,8 @@ def test_3d_config5_shape_properties():
 @pytest.mark.parametrize("B,D,H,W,N", [(1, 8, 8, 64, 2),        # one tile, two steps
                                        (2, 20, 30, 200, 12),    # several tiles in z, y and x; ragged extents; two volumes
                                        (1, 32, 160, 304, 4),    # config-5 cross-section, two chunks along x (halo recomputation at the cut)
-                                       (1, 32, 160, 152, 3)])   # config-5 cross-section: 80 tile columns, 3 x-tiles per chunk
+                                       (1, 32, 160, 152, 3),    # config-5 cross-section: 80 tile columns, 3 x-tiles per chunk
+                                       (2, 10, 9, 68, 4)])      # W % 8 == 4: the volume ends inside a thread's first quad
 def test_3d_persistent_vs_stepwise_and_oracle(B, D, H, W, N):
     """the persistent kernel (gates resident in registers across the steps, neighbour flags between tiles, chunks with
     n_iter halo) against the one-launch-per-step kernel on every voxel, and against the 3D oracle where that is quick"""
