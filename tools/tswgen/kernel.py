@@ -26,10 +26,19 @@ LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 64 * RING_REC
 # ([8 slots][2 halves] dwords, at TAG_RT).  Inside the range the C++ preamble zero-fills: tag 0 is never expected.
 LDS_TAGS = LDS_RING + 8 * RING_SLOT
 TAG_RT = 128
-LDS_TAB = LDS_TAGS + 256             # the workgroup's row-descriptor table (written by the C++ part of the kernel)
-TAB_MAX_ROWS = 2800
+LDS_TAB = LDS_TAGS                   # the workgroup's row-descriptor table (written by the C++ part of the kernel)
+TAB_MAX_ROWS = 2816
 LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES   # 160 KB
 assert LDS_BYTES <= 163840
+
+
+def configure(tag_area):
+    """LDS map with / without the 256-byte tag area of cfg elastic in front of the descriptor table.  The product map has none:
+    with the table 256 bytes higher the loop measured 0.5 .. 1 % slower (profiles/r02_ablations_l_elastic.txt)."""
+    global LDS_TAB, TAB_MAX_ROWS, LDS_BYTES
+    LDS_TAB = LDS_TAGS + (256 if tag_area else 0)
+    TAB_MAX_ROWS = 2800 if tag_area else 2816
+    LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
 
@@ -1112,6 +1121,7 @@ class Gen(object):
 
 def build(cfg, sched=True):
     from . import isa
+    assert (LDS_TAB != LDS_TAGS) == bool(cfg.get("elastic", False)), "configure(tag_area) must match cfg elastic"
     isa.SOFT_VALU_LATENCY = cfg.get("soft_lat", 1)
     g = Gen(cfg)
     p = g.build()

@@ -30,6 +30,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     hinv = None
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
+    K.configure(elastic)
     prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, s8=s8, elastic=elastic), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
@@ -88,6 +89,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         for w in emu.waves:
             for k, v in w.icount.items():
                 icount[k] = icount.get(k, 0) + v
+    K.configure(False)
     out = mem[off["out"]:off["out"] + blur.nbytes].view(np.float32).reshape(blur.shape)
     if hin:
         # oracle for a continuation pass: propagate hinv with blur as H0 ... the oracle has no such entry; emulate with numpy
