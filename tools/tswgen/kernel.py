@@ -36,8 +36,10 @@ def configure(tag_area):
     """LDS map with / without the 256-byte tag area of cfg elastic in front of the descriptor table.  The product map has none:
     with the table 256 bytes higher the loop measured 0.5 .. 1 % slower (profiles/r02_ablations_l_elastic.txt)."""
     global LDS_TAB, TAB_MAX_ROWS, LDS_BYTES
-    LDS_TAB = LDS_TAGS + (256 if tag_area else 0)
-    TAB_MAX_ROWS = 2800 if tag_area else 2816
+    import os
+    shift = int(os.environ.get("TSW_TAB_SHIFT", "0"))   # experiment: where the table starts (multiple of 16 bytes)
+    LDS_TAB = LDS_TAGS + (256 if tag_area else 0) + shift
+    TAB_MAX_ROWS = (2800 if tag_area else 2816) - shift // 16
     LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
@@ -1121,7 +1123,7 @@ class Gen(object):
 
 def build(cfg, sched=True):
     from . import isa
-    assert (LDS_TAB != LDS_TAGS) == bool(cfg.get("elastic", False)), "configure(tag_area) must match cfg elastic"
+    assert (LDS_TAB - LDS_TAGS) % 512 == (256 if cfg.get("elastic", False) else 0), "configure(tag_area) must match cfg elastic"
     isa.SOFT_VALU_LATENCY = cfg.get("soft_lat", 1)
     g = Gen(cfg)
     p = g.build()
