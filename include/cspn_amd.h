@@ -118,15 +118,17 @@ int cspn2d_backward_history_f32(const float* guidance, const float* blur, const 
  * reference cspn_paddle/demo.py:41-43,50-52 (kernel_size == 3 only, demo.py:90)
  *   gate [B,26,D,H,W], feat [B,1,D,H,W], sparse [B,1,D,H,W] or NULL, out [B,1,D,H,W] */
 size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter);   /* enough for every mode */
-/* what this particular call needs with 16-byte aligned tensors (norm NONE without a mask: two value volumes; the folding
- * modes, and misaligned tensors: 29 = cspn3d_workspace_bytes) */
+/* what this particular call needs with 16-byte aligned tensors (norm NONE without a mask: two value volumes + the exchange
+ * buffers of the persistent kernel, ~14 MB; the folding modes, and misaligned tensors: 27 planes more = cspn3d_workspace_bytes) */
 size_t cspn3d_workspace_bytes_ex(int B, int D, int H, int W, int n_iter, int norm_type, int has_sparse);
 int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse, float* out,
                        int B, int D, int H, int W, int n_iter, int norm_type,
                        void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 /* algo: AUTO keeps the 26 gates of every voxel in registers across all n_iter steps (persistent kernel, one pass over the
- * gate tensor per forward) when the call is the Paddle contract (norm NONE, no mask, W % 4 == 0, 16-byte aligned tensors,
- * 2 <= n_iter <= 60); STEPWISE = one launch and one pass over the gates per step. */
+ * gate tensor per forward) when W % 4 == 0, the tensors are 16-byte aligned and 2 <= n_iter <= 60 -- the Paddle contract
+ * (norm NONE, no mask) directly, the normalising / masked modes after one folding pass; STEPWISE = one launch and one pass
+ * over the gates (or the 27 folded planes) per step.  The persistent kernel needs all of its workgroups resident at once
+ * (cooperative launch): one process per GPU. */
 enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 2 };
 int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
