@@ -16,6 +16,7 @@
 // Only the Paddle contract (norm NONE, no sparse mask, W % 4 == 0, 16-byte aligned tensors); other modes run
 // cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
 #include <cstdlib>
+#include <mutex>
 
 #include "cspn_common.h"
 
@@ -586,23 +587,45 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
     hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    // Every workgroup waits for its neighbours' publications, so all of them must be resident at once: a cooperative launch
-    // makes the runtime check that and keeps two such kernels (other streams of this process) from being interleaved on
-    // the device, where each would hold the CUs the other is waiting for.
+    // Every workgroup waits for its neighbours' publications, so all of them must be resident at once, and two such kernels must
+    // never be interleaved on the device (each would hold the CUs the other is waiting for).  Kernels of this process are kept
+    // apart with an event: a launch waits for the previous persistent launch (whatever stream it went to) and records itself.
+    // Other work that happens to occupy CUs only delays the start.  CSPN_3D_COOP_LAUNCH=1 uses hipLaunchCooperativeKernel
+    // instead (the runtime then checks the residency too; ~23 us per launch, 0.905 -> 0.928 ms at config 5).  A stream that is
+    // being captured into a graph takes a plain launch: the replaying graph is the caller's to keep alone on the device.
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<true, false, true>
                    : adjoint ? (const void*)cspn3d_persistent_kernel<true, true, false>
                              : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false, false>
                                                       : (const void*)cspn3d_persistent_kernel<true, false, false>);
-    // (costs ~23 us per launch against a plain launch, 0.905 -> 0.928 ms at config 5; CSPN_3D_PLAIN_LAUNCH=1 for the A/B)
-    static const bool plain_env = getenv("CSPN_3D_PLAIN_LAUNCH") != nullptr;
-    // a stream that is being captured into a graph cannot take a cooperative launch: plain launch there (the replaying graph
-    // is the only thing on its stream; co-residency is the caller's business, as for any captured work)
+    static const bool coop = getenv("CSPN_3D_COOP_LAUNCH") != nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    const bool plain = plain_env || capturing;
-    e = plain ? hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st) : hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
-    if (e != hipSuccess) { set_error("hipLaunchCooperativeKernel(cspn3d_persistent_kernel): %s", hipGetErrorString(e)); return (int)e; }
+    if (coop && !capturing) {
+        e = hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+    } else if (capturing) {
+        e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+    } else {
+        static std::mutex mu;
+        static hipEvent_t last[64] = {};
+        static hipStream_t last_stream[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!last[dev]) {
+            e = hipEventCreateWithFlags(&last[dev], hipEventDisableTiming);
+            if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); return (int)e; }
+        } else if (last_stream[dev] != st) {
+            e = hipStreamWaitEvent(st, last[dev], 0);
+            if (e != hipSuccess) { set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+        if (e == hipSuccess) {
+            e = hipEventRecord(last[dev], st);
+            last_stream[dev] = st;
+        }
+    }
+    if (e != hipSuccess) { set_error("launch of cspn3d_persistent_kernel: %s", hipGetErrorString(e)); return (int)e; }
     return check_launch("cspn3d_persistent_kernel");
 }
 

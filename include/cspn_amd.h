@@ -127,8 +127,8 @@ int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse
 /* algo: AUTO keeps the 26 gates of every voxel in registers across all n_iter steps (persistent kernel, one pass over the
  * gate tensor per forward) when W % 4 == 0, the tensors are 16-byte aligned and 2 <= n_iter <= 60 -- the Paddle contract
  * (norm NONE, no mask) directly, the normalising / masked modes after one folding pass; STEPWISE = one launch and one pass
- * over the gates (or the 27 folded planes) per step.  The persistent kernel needs all of its workgroups resident at once
- * (cooperative launch): one process per GPU. */
+ * over the gates (or the 27 folded planes) per step.  The persistent kernel needs all of its workgroups resident at once;
+ * launches of one process are chained so that two of them never share the device: one process per GPU. */
 enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 2 };
 int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
