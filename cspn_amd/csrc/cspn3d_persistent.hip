@@ -4,17 +4,19 @@
 //
 // Why a persistent kernel: a step needs all 26 gates of every voxel (104 B/voxel); fusing steps means keeping them on chip.
 // One CU holds 4096 voxels' gates in its register file (512 threads x 8 voxels x 26 floats = 416 KB of the 512 KB), the
-// whole device about one million: a "chunk" -- an x-slab of one volume, cut with n_iter halo voxels on each interior side
-// -- is loaded once, all n_iter steps run on it while the gates stay in registers, then the next chunk is taken.  Between
-// steps only the VALUES move (4 B/voxel): every workgroup writes its tile's new level to a scratch volume with memory-side
-// (sc1) stores, raises a per-tile step flag, waits for the flags of its up to 26 neighbour tiles and reads its one-voxel halo
-// shell back with sc1 loads -- no fences, no grid-wide barrier inside a chunk (tools/ubench_gridsync.hip: 4.5 us per step
-// for this exchange vs 10.3 us for a device-wide counter barrier).  Garbage from the cut faces of a chunk travels one voxel
-// per step and stays inside the halo.  HBM traffic = 112 B/voxel x (1 + 2*n_iter / owned x-extent) once, independent of
-// n_iter, plus 8 B/voxel/step of L2/MALL-level value traffic.
+// whole device about one million: a "chunk" -- an x-slab of the batch's volumes standing side by side along x (four
+// never-valid columns between two volumes, so nothing flows across), cut with n_iter halo voxels on each interior side --
+// is loaded once, all n_iter steps run on it while the gates stay in registers, then the next chunk is taken.  Between steps
+// only the VALUES move: a thread of a boundary row publishes its new values as 16-byte quads = three values + the step tag
+// (memory-side sc1 stores), a reader polls the quads it needs until the tag is the step's and drops the values into its LDS
+// halo -- no store acknowledgement, no flags, no barrier between tiles or chunks (the first version of this
+// file exchanged whole levels through scratch volumes with per-tile flags: profiles/r02_vol3d_kernel_stats.md history).
+// Garbage from the cut faces of a chunk travels one voxel per step and stays inside the halo.  HBM traffic = 112 B/voxel x
+// (1 + 2*n_iter / owned x-extent) once, independent of n_iter, plus the exchanged quads.
 //
-// Only the Paddle contract (norm NONE, no sparse mask, W % 4 == 0, 16-byte aligned tensors); other modes run
-// cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
+// Takes W % 4 == 0, W >= 64, 16-byte aligned tensors, 2 <= n_iter <= 60: the Paddle contract (norm NONE, no mask) directly, the
+// normalising / masked modes after fold3d_kernel (HASC), and the transposed operator of the backward (ADJ).  Everything else
+// runs cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
 #include <cstdlib>
 #include <mutex>
 
@@ -41,7 +43,8 @@ struct Geo3 {
     int B, D, H, W, n_iter, halo;
     int tz, ty, cx;          // tiles along z, y (whole extent) and along x per chunk
     int S;                   // owned x-extent of a chunk
-    int nchunk;              // chunks per volume
+    int nchunk;              // chunks per launch: the volumes stand side by side along x, `pitch` columns apart (>= W + 4: the
+    int pitch, vw;           // columns between them are never inside a volume, so nothing flows across), vw = B pitch - 4
     int n_wg;                // workgroups launched (>= tz * ty * cx)
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
     long long gps, gbs;      // gate plane / batch stride in floats: [B][26][V] as given (V, 26 V) or folded planes [26][B][V] (B V, V)
@@ -54,27 +57,7 @@ __device__ __forceinline__ void st16_sc1(float* p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
 }
 
-// device-wide barrier between chunks: workgroups of one XCD (id % 8) count on an XCD-local counter with L2-level atomics,
-// the last arriver of each XCD counts on the device counter, everybody polls that one (tools/ubench_gridsync.hip mode 4)
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned epoch, int n_wg, unsigned* err) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned x = blockIdx.x & 7, per_x = (unsigned)(n_wg + 7 - (int)x) / 8;
-        const unsigned old = __hip_atomic_fetch_add(bar + 64 * (x + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((old + 1) % per_x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = epoch * (unsigned)(n_wg < 8 ? n_wg : 8);
-        unsigned n = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++n > SPIN_MAX) { *err = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-// published boundary of a tile, TAGGED exchange, in 16-byte quads = up to three values + the step tag in the fourth word.  Thread xg
+// published boundary of a tile, in 16-byte quads = up to three values + the step tag in the fourth word.  Thread xg
 // of row (lz, ly) owns the quads q3 = 0, 1, 2 of its values (0,1,2) (3,4,5) (6,7), stored at [q3][row][xg] so that a wave's store (and
 // a reader's load) covers whole 128-byte lines; written for boundary rows only.  The x faces (value 0 of xg = 0, value 7 of xg = 7)
 // of ALL rows follow at [side][row], one value per quad.
@@ -99,7 +82,7 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // the gate gradient multiplies with).
 // HASC: a constant term per voxel, H_{t+1} = c' + sum_k w'_k H_t(p + off_k): the folded form of the normalising / masked modes
 // (fold3d_kernel of cspn3d_stepwise.hip writes w' and c'); c' of the thread's eight voxels waits in LDS between the steps.
-template <bool TAGGED, bool ADJ, bool HASC>
+template <bool ADJ, bool HASC>
 __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
                                                                  const float* __restrict__ cprime, float* __restrict__ out,
                                                                  float* __restrict__ levels, float* __restrict__ scratch,
@@ -107,9 +90,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(16))) float lds[2 * LTILE];
     __shared__ __attribute__((aligned(16))) float4 s_c[HASC ? 2 * NTP : 1];   // c' of the thread's two quads, [quad][thread]
     __shared__ int s_bail;
-    unsigned* flags = sync;                  // [MAX_WG] per-tile step flags
-    unsigned* bar = sync + MAX_WG;           // [64 * 9] barrier counters (one cache line each)
-    unsigned* err = sync + MAX_WG + 64 * 9;  // [1]
+    unsigned* err = sync + MAX_WG + 64 * 9;  // [1] (the words in front of it belonged to the flag exchange of the first version)
 #ifdef P3_TRACE
     unsigned long long* trc = reinterpret_cast<unsigned long long*>(sync + 2048);   // [n_iter][6] stamps of workgroup 37, chunk 1
 #define P3_STAMP(k) if (wg == 37 && tid == 0 && round == 1) trc[(it - 1) * 6 + (k)] = __builtin_readcyclecounter()
@@ -120,27 +101,29 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     const int tid = threadIdx.x, wg = blockIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
-    float* P[2] = {scratch, scratch + total};
-    float4* X = reinterpret_cast<float4*>(scratch + 2 * total);   // TAGGED: [2][n_wg][NQ] published boundaries
+    float4* X = reinterpret_cast<float4*>(scratch + 2 * total);   // [2][n_wg][NQ] published boundaries
     const int tiles = g.tz * g.ty * g.cx;
     const bool have_tile = wg < tiles;
     const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
     if (tid == 0) s_bail = 0;
-    // neighbour tile of this thread (threads 0..25), -1: none inside the chunk window
-    int nb = -1;
-    if (tid < 26 && have_tile) {
-        const int c = tid < 13 ? tid : tid + 1;
-        const int nz = iz + c / 9 - 1, ny = iy + (c / 3) % 3 - 1, nx = ix + c % 3 - 1;
-        if (nz >= 0 && nz < g.tz && ny >= 0 && ny < g.ty && nx >= 0 && nx < g.cx) nb = (nz * g.ty + ny) * g.cx + nx;
-    }
-    unsigned epoch = 0;
-    for (int b = 0; b < g.B; ++b) {
+    {
         for (int c = 0; c < g.nchunk; ++c) {
-            const unsigned round = (unsigned)(b * g.nchunk + c);
+            const unsigned round = (unsigned)c;
             if (have_tile) {
-                const int ox0 = c * g.S, ox1 = min(g.W, ox0 + g.S);     // owned columns of the chunk
+                // x coordinates below are positions on the row of volumes (volume b starts at b * pitch)
+                const int ox0 = c * g.S, ox1 = min(g.vw, ox0 + g.S);    // owned columns of the chunk
                 const int wx0 = ox0 - g.halo;                            // window start (may be negative)
                 const int z0 = iz * TZ, y0 = iy * TY, x0 = wx0 + ix * TX;
+                // position -> (volume, column in it): pitch >= TX + 2, so a tile and its shell lie across one volume boundary
+                // at most -- one scalar division per chunk, a compare per lane
+                const int bf = __builtin_amdgcn_readfirstlane(x0 > 0 ? x0 / g.pitch : 0);   // (keeps it in a scalar register)
+                const int xbf = bf * g.pitch;
+                auto loc = [&](int xv, int& bb, int& xx) {
+                    const int xr = xv - xbf;
+                    const bool wr = xr >= g.pitch;
+                    bb = bf + (wr ? 1 : 0);
+                    xx = wr ? xr - g.pitch : xr;
+                };
                 P3_CHUNK(0);
                 // ---- level 0 first (its loads are issued ahead of the gates' so that they return first): the thread's own eight
                 // voxels and its share of the 2504-voxel halo shell (outside the volume: 0, for good; outside the chunk window:
@@ -156,11 +139,17 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 int tc = tid;   // opaque per chunk: nothing below may be hoisted out of the chunk loop (it would be spilled, and a
                 asm volatile("" : "+v"(tc));   // spill reload waits for every load in flight)
                 const int lx = (tc & (XG - 1)) * 8, ly = (tc >> XGS) & 7, lz = tc >> (XGS + 3);
-                const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+                const int z = z0 + lz, y = y0 + ly;
+                int b0, xq0, b1, xq1;     // the thread's two quads: volume and first column
+                loc(x0 + lx, b0, xq0);
+                loc(x0 + lx + 4, b1, xq1);
                 const bool in_zy = z < g.D && y < g.H;
-                const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
-                const unsigned voff = (unsigned)((z * g.H + y) * g.W + x) * 4u;
-                const unsigned voff0 = in0 ? voff : 0u, voff1 = in1 ? voff + 16u : 0u;
+                const bool in0 = in_zy && xq0 >= 0 && xq0 + 3 < g.W && b0 < g.B, in1 = in_zy && xq1 >= 0 && xq1 + 3 < g.W && b1 < g.B;
+                const int row = (z * g.H + y) * g.W;
+                // byte offsets: 1-channel tensors (feat, c') and the gate tensor (volume stride gbs floats)
+                const unsigned fo0 = in0 ? (unsigned)(b0 * (int)V + row + xq0) * 4u : 0u, fo1 = in1 ? (unsigned)(b1 * (int)V + row + xq1) * 4u : 0u;
+                const unsigned go0 = (unsigned)(b0 * (int)g.gbs + row + xq0) * 4u, go1 = (unsigned)(b1 * (int)g.gbs + row + xq1) * 4u;
+                const unsigned voff0 = in0 ? go0 : 0u, voff1 = in1 ? go1 : 0u;
                 auto shell_pos = [&](int i, int& pz, int& py, int& px) {
                     if (i < SH_Z) { pz = i < LY * LXU ? 0 : LZ - 1; const int r = i < LY * LXU ? i : i - LY * LXU; py = r / LXU; px = r - py * LXU; }
                     else if (i < SH_Z + SH_Y) { const int u = i - SH_Z, r = u / LXU; px = u - r * LXU; pz = 1 + (r >> 1); py = (r & 1) ? LY - 1 : 0; }
@@ -168,41 +157,43 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 };
                 v4f f0, f1;
                 float fs[NSHT];
-                const float* fb = feat + (size_t)b * V;
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f0) : "v"(voff0), "s"(fb) : "memory");
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f1) : "v"(voff1), "s"(fb) : "memory");
+                const float* fb = feat;
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f0) : "v"(fo0), "s"(fb) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(f1) : "v"(fo1), "s"(fb) : "memory");
 #pragma unroll
                 for (int j = 0; j < NSHT; ++j) {
                     const int i = tc + j * NTP;
                     int pz, py, px;
                     shell_pos(i, pz, py, px);
-                    const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
-                    const bool ok = i < NSH && vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
-                    const unsigned so = ok ? (unsigned)((vz * g.H + vy) * g.W + vx) * 4u : 0u;
+                    const int vz = z0 + pz - 1, vy = y0 + py - 1;
+                    int vb, vx;
+                    loc(x0 + px - 1, vb, vx);
+                    const bool ok = i < NSH && vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W && vb < g.B;
+                    const unsigned so = ok ? (unsigned)(vb * (int)V + (vz * g.H + vy) * g.W + vx) * 4u : 0u;
                     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(fs[j]) : "v"(so), "s"(fb) : "memory");
                 }
                 v4f cq0, cq1;
                 if (HASC) {
-                    const float* cb = cprime + (size_t)b * V;
-                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq0) : "v"(voff0), "s"(cb) : "memory");
-                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq1) : "v"(voff1), "s"(cb) : "memory");
+                    const float* cb = cprime;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq0) : "v"(fo0), "s"(cb) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(cq1) : "v"(fo1), "s"(cb) : "memory");
                 }
                 // ---- the 26 gates of the thread's eight voxels: read once, kept in registers for all steps
                 v4f w[26][2];
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
-                    const float* gk = gate + (size_t)b * g.gbs + (size_t)k * g.gps;
+                    const float* gk = gate + (size_t)k * g.gps;
                     if (ADJ) {
                         const int c27 = k < 13 ? k : k + 1, dz = 1 - c27 / 9, dy = 1 - (c27 / 3) % 3, dx = 1 - c27 % 3;
                         const int ko = (26 - c27) < 13 ? (26 - c27) : (26 - c27) - 1;   // the plane of the opposite offset
-                        const float* gko = gate + (size_t)b * g.gbs + (size_t)ko * g.gps;
+                        const float* gko = gate + (size_t)ko * g.gps;
                         const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
                         const int sh = ((dz * g.H + dy) * g.W) * 4;
                         // first / last element outside the volume: read the aligned quad, shift afterwards
-                        const int e0 = (dx < 0 && x == 0) || (dx > 0 && x + 4 == g.W) ? 0 : dx * 4;
-                        const int e1 = (dx < 0 && x + 4 == 0) || (dx > 0 && x + 8 == g.W) ? 0 : dx * 4;
-                        const unsigned a0 = in0 && rowok ? (unsigned)((int)voff + sh + e0) : 0u;
-                        const unsigned a1 = in1 && rowok ? (unsigned)((int)voff + 16 + sh + e1) : 0u;
+                        const int e0 = (dx < 0 && xq0 == 0) || (dx > 0 && xq0 + 4 == g.W) ? 0 : dx * 4;
+                        const int e1 = (dx < 0 && xq1 == 0) || (dx > 0 && xq1 + 4 == g.W) ? 0 : dx * 4;
+                        const unsigned a0 = in0 && rowok ? (unsigned)((int)go0 + sh + e0) : 0u;
+                        const unsigned a1 = in1 && rowok ? (unsigned)((int)go1 + sh + e1) : 0u;
                         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(a0), "s"(gko) : "memory");
                         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(a1), "s"(gko) : "memory");
                     } else {
@@ -210,7 +201,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
 #elif defined(P3_EXP_LANE_REMAP)   // WRONG RESULTS: each instruction reads 128 contiguous bytes per row
-                    const int xa = x0 + (tc & (XG - 1)) * 4;
+                    const int xa = x0 + (tc & (XG - 1)) * 4;   // (single volume only)
                     const unsigned ra = (unsigned)((z * g.H + y) * g.W + xa) * 4u;
                     const unsigned r0_ = (in_zy && xa >= 0 && xa + 3 < g.W) ? ra : 0u, r1_ = (in_zy && xa + 32 >= 0 && xa + 35 < g.W) ? ra + 128u : 0u;
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(r0_), "s"(gk) : "memory");
@@ -237,9 +228,12 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
                     const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
-                    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+                    const int z = z0 + lz, y = y0 + ly;
+                    int b0, xq0, b1, xq1;
+                    loc(x0 + lx, b0, xq0);
+                    loc(x0 + lx + 4, b1, xq1);
                     const bool in_zy = z < g.D && y < g.H;
-                    const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
+                    const bool in0 = in_zy && xq0 >= 0 && xq0 + 3 < g.W && b0 < g.B, in1 = in_zy && xq1 >= 0 && xq1 + 3 < g.W && b1 < g.B;
                     const int o = ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
                     const float own8[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
@@ -253,8 +247,10 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int i = tid_ + j * NTP;
                         int pz, py, px;
                         shell_pos(i, pz, py, px);
-                        const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
-                        const bool ok = vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
+                        const int vz = z0 + pz - 1, vy = y0 + py - 1;
+                        int vb, vx;
+                        loc(x0 + px - 1, vb, vx);
+                        const bool ok = vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W && vb < g.B;
                         if (i < NSH) {
                             const float v = ok ? fs[j] : 0.f;
                             lds[(pz * LY + py) * LX + px] = v;
@@ -273,11 +269,11 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
                         v4f q0 = in0 && rowok ? w[k][0] : zero, q1 = in1 && rowok ? w[k][1] : zero;
                         if (dx < 0) {   // element 0 is the voxel left of the volume
-                            if (x == 0) q0 = v4f{0.f, q0.x, q0.y, q0.z};
-                            if (x + 4 == 0) q1 = v4f{0.f, q1.x, q1.y, q1.z};
+                            if (xq0 == 0) q0 = v4f{0.f, q0.x, q0.y, q0.z};
+                            if (xq1 == 0) q1 = v4f{0.f, q1.x, q1.y, q1.z};
                         } else if (dx > 0) {   // element 3 is the voxel right of the volume
-                            if (x + 4 == g.W) q0 = v4f{q0.y, q0.z, q0.w, 0.f};
-                            if (x + 8 == g.W) q1 = v4f{q1.y, q1.z, q1.w, 0.f};
+                            if (xq0 + 4 == g.W) q0 = v4f{q0.y, q0.z, q0.w, 0.f};
+                            if (xq1 + 4 == g.W) q1 = v4f{q1.y, q1.z, q1.w, 0.f};
                         }
                         w[k][0] = q0;
                         w[k][1] = q1;
@@ -334,28 +330,33 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     // voxels outside the volume have zero gates: their value stays 0
                     const float4 r0 = make_float4(acc[0], acc[1], acc[2], acc[3]), r1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
-                    const bool in_zy = z < g.D && y < g.H;
-                    const bool in0 = in_zy && x >= 0 && x + 3 < g.W, in1 = in_zy && x + 4 >= 0 && x + 7 < g.W;
-                    const size_t vox = (size_t)b * V + ((size_t)z * g.H + y) * g.W + x;
+                    // the owned voxels of a level go to memory only in the last step (and, for the backward, as level history):
+                    // where they go is worked out inside those (uniform) branches, the registers are needed elsewhere
+                    auto store_owned = [&](float* dst) {
+                        const int z = z0 + lz, y = y0 + ly, x = x0 + lx;   // x: position on the row of volumes
+                        if (z >= g.D || y >= g.H) return;
+                        const int row = (z * g.H + y) * g.W;
+                        int bb, xx;
+                        loc(x, bb, xx);
+                        if (xx >= 0 && xx + 3 < g.W && bb < g.B && x >= ox0 && x < ox1)
+                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * (int)V + row + xx)) = r0;
+                        loc(x + 4, bb, xx);
+                        if (xx >= 0 && xx + 3 < g.W && bb < g.B && x + 4 >= ox0 && x + 4 < ox1)
+                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * (int)V + row + xx)) = r1;
+                    };
                     if (it == g.n_iter) {
-                        if (in0 && x >= ox0 && x < ox1) *reinterpret_cast<float4*>(out + vox) = r0;
-                        if (in1 && x + 4 >= ox0 && x + 4 < ox1) *reinterpret_cast<float4*>(out + vox + 4) = r1;
+                        store_owned(out);
                         break;
                     }
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
-                    if (levels) {   // the level history of the backward: owned voxels only
-                        float* lv = levels + (size_t)(g.lv0 + it * g.lvs) * total + vox;
-                        if (in0 && x >= ox0 && x < ox1) *reinterpret_cast<float4*>(lv) = r0;
-                        if (in1 && x + 4 >= ox0 && x + 4 < ox1) *reinterpret_cast<float4*>(lv + 4) = r1;
-                    }
+                    if (levels) store_owned(levels + (size_t)(g.lv0 + it * g.lvs) * total);   // the level history of the backward
                     P3_STAMP(1);
-                    // TAGGED: publications are numbered through the whole launch and alternate between the two buffers, so the
+                    // publications are numbered through the whole launch and alternate between the two buffers, so the
                     // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
-                    const unsigned target = TAGGED ? round * (unsigned)(g.n_iter - 1) + (unsigned)it : round * 64u + (unsigned)it;
-                    if (TAGGED) {
+                    const unsigned target = round * (unsigned)(g.n_iter - 1) + (unsigned)it;
+                    {
                         // ---- publish the tile's boundary straight from the registers as self-validating 16-byte quads (up to three
                         // values + the step tag): no wait for the stores, no flag, no barrier -- a reader polls the quad it needs
                         // until the tag is the step's.  A thread's eight values are the quads (0,1,2) (3,4,5) (6,7) of its row;
@@ -449,80 +450,13 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             }
                             if (pend && ++tries > SPIN_MAX) { *err = 2; s_bail = 1; break; }
                         }
-                    } else {
-                    if (in0) st16_sc1(P[it & 1] + vox, r0);
-                    if (in1) st16_sc1(P[it & 1] + vox + 4, r1);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    P3_STAMP(2);
-                    if (tid == 0) __hip_atomic_store(flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (nb >= 0) {
-                        unsigned n = 0;
-                        while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                            if (++n > SPIN_MAX) { *err = 2; s_bail = 1; break; }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    __syncthreads();
-                    P3_STAMP(3);
-                    // ---- the halo shell of the new level, memory-side loads, all of a thread's requests in flight together:
-                    // 36 face rows (two z faces of 10 rows, two y faces of 8) of 64 interior columns as 16-byte loads (576), the
-                    // two end columns of those rows (72) and the two x faces (128) as single words.  Only voxels of neighbour tiles
-                    // inside the window and the volume are read; the rest keeps its initial value.
-                    const float* src = P[it & 1] + (size_t)b * V;
-                    constexpr int NROW = 2 * LY + 2 * TZ, NV4 = NROW * (TX / 4), NEND = 2 * NROW, NXF = 2 * TZ * TY, NITEM = NV4 + NEND + NXF;
-                    constexpr int NSLOT = (NITEM + NTP - 1) / NTP;
-                    v4f hv[NSLOT];
-                    int hl[NSLOT];   // LDS float index, bit 30: a quad; -1: nothing to fetch
-#pragma unroll
-                    for (int j = 0; j < NSLOT; ++j) {
-                        const int item = tid_ + j * NTP;
-                        hl[j] = -1;
-                        hv[j] = v4f{0.f, 0.f, 0.f, 0.f};
-                        if (item >= NITEM) continue;
-                        int pz, py, px, n4 = 0;
-                        if (item < NV4 + NEND) {
-                            const bool v4 = item < NV4;
-                            const int rr = v4 ? item / (TX / 4) : (item - NV4) >> 1;     // face row 0..35
-                            if (rr < 2 * LY) { pz = rr < LY ? 0 : LZ - 1; py = rr < LY ? rr : rr - LY; }
-                            else { const int q = rr - 2 * LY; py = q < TZ ? 0 : LY - 1; pz = 1 + (q < TZ ? q : q - TZ); }
-                            if (v4) { px = 1 + 4 * (item - rr * (TX / 4)); n4 = 1; }
-                            else px = ((item - NV4) & 1) ? LXU - 1 : 0;
-                        } else {
-                            const int q = item - NV4 - NEND, f = q / (TZ * TY), r = q - f * (TZ * TY);
-                            px = f ? LXU - 1 : 0; pz = 1 + r / TY; py = 1 + r - (pz - 1) * TY;
-                        }
-                        const int vz = z0 + pz - 1, vy = y0 + py - 1, vx = x0 + px - 1;
-                        const int tz2 = iz + (pz == 0 ? -1 : (pz == LZ - 1 ? 1 : 0)), ty2 = iy + (py == 0 ? -1 : (py == LY - 1 ? 1 : 0)),
-                                  tx2 = ix + (px == 0 ? -1 : (px == LXU - 1 ? 1 : 0));
-                        if (tz2 < 0 || tz2 >= g.tz || ty2 < 0 || ty2 >= g.ty || tx2 < 0 || tx2 >= g.cx) continue;
-                        if (vz < 0 || vz >= g.D || vy < 0 || vy >= g.H || vx < 0 || vx >= g.W) continue;   // (x0 % 4 == 0: a quad is in or out)
-                        const float* gp = src + ((size_t)vz * g.H + vy) * g.W + vx;
-                        hl[j] = ((pz * LY + py) * LX + px) | (n4 << 30);
-                        if (n4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hv[j]) : "v"(gp) : "memory");
-                        else asm volatile("global_load_dword %0, %1, off sc1" : "=v"(hv[j].x) : "v"(gp) : "memory");
-                    }
-#pragma unroll
-                    for (int j = 0; j < NSLOT; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[j]) : : "memory");
-#pragma unroll
-                    for (int j = 0; j < NSLOT; ++j) {
-                        if (hl[j] < 0) continue;
-                        float* lp = nxt + (hl[j] & 0x3fffffff);
-                        lp[0] = hv[j].x;
-                        if (hl[j] >> 30) { lp[1] = hv[j].y; lp[2] = hv[j].z; lp[3] = hv[j].w; }
-                    }
                     }
                     __syncthreads();
                     P3_STAMP(4);
-                    if (s_bail) {
-                        if (TAGGED) return;   // a neighbour never published (error word set): nothing below can complete
-                        break;
-                    }
+                    if (s_bail) return;   // a neighbour never published (error word set): nothing below can complete
                 }
                 P3_CHUNK(3);
             }
-            ++epoch;
-            if (!TAGGED && (b + 1 < g.B || c + 1 < g.nchunk)) grid_barrier(bar, epoch, g.n_wg, err);   // scratch and tiles are reused
         }
     }
 }
@@ -548,10 +482,12 @@ Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
     g.ty = (H + TY - 1) / TY;
     const int per_col = g.tz * g.ty;
     g.cx = per_col > 0 ? resident_wgs() / per_col : 0;
-    const int need = (W + 2 * g.halo + TX - 1) / TX;     // x-tiles that cover a whole row plus halos: no need for more
+    g.pitch = W + 4;                  // the volumes of the batch side by side along x, four never-valid columns between them
+    g.vw = B * g.pitch - 4;
+    const int need = (g.vw + 2 * g.halo + TX - 1) / TX;     // x-tiles that cover the whole row plus halos: no need for more
     if (g.cx > need) g.cx = need;
     g.S = g.cx * TX - 2 * g.halo;
-    g.nchunk = g.S > 0 ? (W + g.S - 1) / g.S : 0;
+    g.nchunk = g.S > 0 ? (g.vw + g.S - 1) / g.S : 0;
     g.n_wg = per_col * g.cx;
     return g;
 }
@@ -562,7 +498,9 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || n_iter < 2 || n_iter > 60 || (W % 4) != 0) return false;
     const Geo3 g = make_geo3(B, D, H, W, n_iter);
     // worth it only when a chunk owns clearly more than it recomputes, and the device can hold it
-    return g.cx >= 1 && g.n_wg <= resident_wgs() && g.S >= 4 * g.halo && (long long)B * g.nchunk < (1 << 24);
+    // (lane offsets into the gate tensor are 32-bit byte offsets)
+    return g.pitch >= LXU && g.cx >= 1 && g.n_wg <= resident_wgs() && g.S >= 4 * g.halo && g.nchunk < (1 << 24) &&
+           (long long)B * 26 * D * H * W * 4 < (1LL << 32);
 }
 
 constexpr size_t XBYTES = 2 * (size_t)MAX_WG * NQ * 16;   // published tile boundaries, two level parities
@@ -583,7 +521,6 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     g.gbs = cprime ? (long long)(total / B) : 26LL * (long long)(total / B);
     float* scratch = (float*)ws;
     unsigned* sync = (unsigned*)((char*)(scratch + 2 * total) + XBYTES);
-    static const bool flags_mode = getenv("CSPN_3D_FLAGS") != nullptr;   // A/B switch: the flag-based exchange of the first version
     // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
     hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
@@ -594,10 +531,8 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     // instead (the runtime then checks the residency too; ~23 us per launch, 0.905 -> 0.928 ms at config 5).  A stream that is
     // being captured into a graph takes a plain launch: the replaying graph is the caller's to keep alone on the device.
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
-    const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<true, false, true>
-                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, true, false>
-                             : (flags_mode && !levels ? (const void*)cspn3d_persistent_kernel<false, false, false>
-                                                      : (const void*)cspn3d_persistent_kernel<true, false, false>);
+    const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
+                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, false> : (const void*)cspn3d_persistent_kernel<false, false>;
     static const bool coop = getenv("CSPN_3D_COOP_LAUNCH") != nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
