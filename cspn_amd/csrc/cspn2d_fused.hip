@@ -584,7 +584,9 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
         if (asm_ok && n == LV) {
-            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
+            if (tsw3_supported(B, H, W, sparse != nullptr, hin != blur)) {
+                if (int e = tsw3_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
+            } else if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
             hin = dst;
             done += n;
             continue;

@@ -60,6 +60,10 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
 bool tsw2d_supported(int B, int H, int W);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
                int W, int norm, hipStream_t st, float* hist = nullptr);
+// ---- the round-3 loop (cspn2d_tsw3.hip): LDS-DMA row slots; forward passes without history ----
+bool tsw3_supported(int B, int H, int W, bool sparse, bool hin_differs);
+int tsw3_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H, int W,
+              int norm, hipStream_t st);
 int guidance_to_sited8(const float* g, float* out, int B, int H, int W, int norm, hipStream_t st);
 int tsw2d_pass_sited8(const float* g8, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm,
                       hipStream_t st);

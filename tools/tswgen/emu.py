@@ -7,7 +7,7 @@ and rounded once (double rounding is far below the 1e-4 parity tolerance).
 """
 import numpy as np
 
-from .isa import R, DS_OPS, VMEM_LD, VMEM_ST, SMEM
+from .isa import R, DS_OPS, VMEM_LD, VMEM_ST, SMEM, VMEM_LDS
 
 F32 = np.float32
 U32 = np.uint32
@@ -23,6 +23,7 @@ class Wave(object):
         self.v = np.zeros((256, 64), U32)
         self.s = np.zeros(128, U32)
         self.scc = 0
+        self.m0 = 0
         self.vcc = np.uint64(0)
         self.exec = np.uint64(0xFFFFFFFFFFFFFFFF)
         self.pc = 0
@@ -54,6 +55,7 @@ class Emu(object):
         self.lds_epoch = np.full(lds_bytes // 4, -1, np.int64)
         self.lds_reader = np.full(lds_bytes // 4, -1, np.int64)  # wave that read it in the current epoch (-2: several)
         self.lds_repoch = np.full(lds_bytes // 4, -1, np.int64)
+        self.lds_dma = np.zeros(lds_bytes // 4, bool)   # dwords an LDS-DMA load in flight will overwrite at an unknown time
         self.epoch = 0
         self.waves = [Wave(w) for w in range(nwaves)]
         self.nsteps = 0
@@ -76,6 +78,8 @@ class Emu(object):
                 return int((int(w.vcc) >> (32 * k)) & 0xffffffff)
             if o.kind == "exec":
                 return int((int(w.exec) >> (32 * k)) & 0xffffffff)
+            if o.kind == "m0":
+                return int(w.m0)
             raise EmuError("scalar read of vector register")
         if isinstance(o, float):
             return int(np.array([o], F32).view(U32)[0])
@@ -100,6 +104,8 @@ class Emu(object):
             cur = int(w.exec)
             cur = (cur & ~(0xffffffff << (32 * k))) | (val << (32 * k))
             w.exec = np.uint64(cur)
+        elif o.kind == "m0":
+            w.m0 = val
         else:
             raise EmuError("scalar write to vector register")
 
@@ -145,6 +151,9 @@ class Emu(object):
         if np.any(idx[lanes] < 0) or np.any(idx[lanes] >= self.lds.size):
             raise EmuError("wave %d pc %d: LDS access out of range %s" % (w.wid, w.pc, self.ins[w.pc].text()))
         idx = np.where(lanes[:, None], idx, 0)
+        if np.any(self.lds_dma[idx[lanes].ravel()]):
+            raise EmuError("wave %d pc %d: LDS access to bytes an LDS-DMA load in flight is still writing: %s" % (
+                w.wid, w.pc, self.ins[w.pc].text()))
         if self.check_races:
             fl = idx[lanes].ravel()
             same = self.lds_epoch[fl] == self.epoch
@@ -178,6 +187,38 @@ class Emu(object):
         idx = (a[:, None] // 4) + np.arange(ndw)[None, :]
         return np.where(lanes[:, None], idx, 1024)
 
+    def lds_dma_load(self, w, ins, ex):
+        """global_load_lds_dwordx4 voff, sbase (M0 = LDS byte address of lane 0's 16 bytes): the data is written some time
+        between now and the vmcnt wait of this wave that covers the load; until then nobody may touch the destination, and
+        other waves only after a barrier behind that wait (modelled as an LDS write of this wave in the epoch of the wait)"""
+        s = ins.src
+        gidx = self.gaddr(w, ins, self.rv(w, s[0]), s[1], 4, ex)
+        dst = int(w.m0) + int(ins.mods.get("offset", 0)) + 16 * np.arange(64, dtype=np.int64)   # (measured: the offset moves both)
+        if int(dst[0]) % 16:
+            raise EmuError("LDS-DMA destination not 16-byte aligned")
+        didx = (dst[:, None] // 4) + np.arange(4)[None, :]
+        if didx.max() >= self.lds.size:
+            raise EmuError("wave %d pc %d: LDS-DMA destination out of range" % (w.wid, w.pc))
+        lanes = ex
+        fl = didx[lanes].ravel()
+        if np.any(self.lds_dma[fl]):
+            raise EmuError("wave %d pc %d: two LDS-DMA loads in flight into the same bytes" % (w.wid, w.pc))
+        if self.check_races:
+            rd = (self.lds_repoch[fl] == self.epoch) & (self.lds_reader[fl] != w.wid)
+            wr = (self.lds_epoch[fl] == self.epoch) & (self.lds_writer[fl] != w.wid)
+            if np.any(rd) or np.any(wr):
+                raise EmuError("wave %d pc %d: LDS-DMA into bytes another wave accessed in this barrier epoch: %s" % (
+                    w.wid, w.pc, ins.text()))
+        data = self.mem32[gidx[lanes]].copy()
+        self.lds_dma[fl] = True
+
+        def land(fl=fl, data=data.ravel(), wid=w.wid):
+            self.lds[fl] = data
+            self.lds_dma[fl] = False
+            self.lds_writer[fl] = wid
+            self.lds_epoch[fl] = self.epoch
+        w.vm_q.append(land)
+
     def _pend(self, w, regs, q):
         for r in regs:
             self._chk(w, r)
@@ -187,6 +228,9 @@ class Emu(object):
             q.append(list(regs))
 
     def _retire(self, w, regs):
+        if callable(regs):   # an LDS-DMA load lands when the wave's vmcnt wait covers it
+            regs()
+            return
         for r in regs:
             w.pending[r] -= 1
 
@@ -256,6 +300,8 @@ class Emu(object):
                 for k in range(ndw):
                     self.wv(w, d[0], self.mem32[idx[:, k]], k)
                 self._pend(w, regs, w.vm_q)
+        elif o in VMEM_LDS:
+            self.lds_dma_load(w, ins, ex)
         elif o in VMEM_ST:
             ndw = {"global_store_dword": 1, "global_store_dwordx2": 2, "global_store_dwordx4": 4}[o]
             idx = self.gaddr(w, ins, self.rv(w, s[0]), s[2], ndw, ex)
@@ -331,6 +377,14 @@ class Emu(object):
             r = (a >> off) & ((1 << width) - 1)
             self.ws(w, d[0], r)
             w.scc = int(r != 0)
+        elif o == "s_bfe_i32":
+            a, b = rs(w, s[0]), rs(w, s[1])
+            off, width = b & 31, (b >> 16) & 0x7f
+            r = (a >> off) & ((1 << width) - 1)
+            if width and (r >> (width - 1)) & 1:
+                r -= 1 << width
+            self.ws(w, d[0], r)
+            w.scc = int((r & 0xffffffff) != 0)
         elif o in ("s_and_b32", "s_or_b32", "s_xor_b32", "s_andn2_b32"):
             a, b = rs(w, s[0]), rs(w, s[1])
             r = {"s_and_b32": a & b, "s_or_b32": a | b, "s_xor_b32": a ^ b, "s_andn2_b32": a & ~b}[o] & 0xffffffff
@@ -449,6 +503,9 @@ class Emu(object):
             elif o == "v_mul_u32_u24":
                 a, b = rv(w, s[0]).astype(np.int64) & 0xffffff, rv(w, s[1]).astype(np.int64) & 0xffffff
                 self.wv(w, d[0], ((a * b) & 0xffffffff).astype(U32))
+            elif o == "v_lshl_add_u32":   # (src0 << src1) + src2
+                a = rv(w, s[0]).astype(np.int64) << (self.rs(w, s[1]) & 31)
+                self.wv(w, d[0], ((a + rv(w, s[2]).astype(np.int64)) & 0xffffffff).astype(U32))
             elif o == "v_mad_u32_u24":
                 a, b = rv(w, s[0]).astype(np.int64) & 0xffffff, rv(w, s[1]).astype(np.int64) & 0xffffff
                 self.wv(w, d[0], ((a * b + rv(w, s[2]).astype(np.int64)) & 0xffffffff).astype(U32))
@@ -457,6 +514,8 @@ class Emu(object):
 
     def ds(self, w, ins, ex):
         o, d, s, m = ins.op, ins.dst, ins.src, ins.mods
+        if not (0 <= m.get("offset", 0) < 65536 and 0 <= m.get("offset0", 0) < 256 and 0 <= m.get("offset1", 0) < 256):
+            raise EmuError("DS offset out of range: %r" % (m,))
         addr = self.rv(w, s[0]).astype(np.int64)
         if o in ("ds_read_b128", "ds_read_b64", "ds_read_b32"):
             ndw = {"ds_read_b128": 4, "ds_read_b64": 2, "ds_read_b32": 1}[o]

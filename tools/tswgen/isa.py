@@ -32,10 +32,12 @@ class R(object):
     def regs(self):
         if self.kind in ("vcc", "exec"):
             return [(self.kind, 0), (self.kind, 1)]
+        if self.kind == "m0":
+            return [("m0", 0)]
         return [(self.kind, self.i + k) for k in range(self.n)]
 
     def text(self):
-        if self.kind in ("vcc", "exec"):
+        if self.kind in ("vcc", "exec", "m0"):
             t = self.kind
         elif self.n == 1:
             t = "%s%d" % (self.kind, self.i)
@@ -61,6 +63,7 @@ def S(i, n=1):
 
 VCC = R("vcc", 0, 2)
 EXEC = R("exec", 0, 2)
+M0 = R("m0", 0, 1)   # LDS destination base of the LDS-DMA loads (global_load_lds_*)
 
 
 def optext(o):
@@ -80,16 +83,18 @@ VOP_TRANS = {"v_rcp_f32"}
 VOP_E32 = {"v_mov_b32", "v_rcp_f32", "v_lshlrev_b32", "v_lshrrev_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32",
            "v_mul_f32", "v_add_f32", "v_sub_f32", "v_mul_u32_u24", "v_xor_b32"}
 VOP_E64 = {"v_fma_f32", "v_cndmask_b32", "v_cmp_ge_u32", "v_cmp_lt_u32", "v_cmp_gt_f32", "v_cmp_lt_f32", "v_cmp_eq_u32", "v_cmp_ne_u32",
-           "v_mad_u32_u24"}
+           "v_mad_u32_u24", "v_lshl_add_u32"}
 DS_OPS = {"ds_read_b128", "ds_write_b128", "ds_write2_b32", "ds_read_b64", "ds_write_b64", "ds_write_b32", "ds_read_b32",
           "ds_read2st64_b32", "ds_write2st64_b32", "ds_read2_b32"}
 VMEM_LD = {"global_load_dwordx2", "global_load_dword", "global_load_dwordx4"}
+# LDS-DMA: no VGPR destination; 64 lanes x 16 bytes land at M0 + 16 * lane.  Operands: [lane offset VGPR, scalar base pair, M0]
+VMEM_LDS = {"global_load_lds_dwordx4"}
 VMEM_ST = {"global_store_dwordx4", "global_store_dwordx2", "global_store_dword"}
 SMEM = {"s_load_dwordx8", "s_load_dwordx4", "s_load_dwordx2", "s_load_dword"}
 BRANCH = {"s_cbranch_scc0", "s_cbranch_scc1", "s_branch", "s_cbranch_execz", "s_cbranch_vccnz", "s_cbranch_vccz"}
 SCC_WRITERS = {"s_add_u32", "s_addc_u32", "s_subb_u32", "s_add_i32", "s_sub_i32", "s_sub_u32", "s_lshl_b32", "s_lshr_b32", "s_and_b32",
                "s_or_b32", "s_xor_b32", "s_andn2_b32", "s_and_b64", "s_or_b64", "s_andn2_b64", "s_and_saveexec_b64",
-               "s_bitcmp1_b32", "s_bitcmp0_b32", "s_ashr_i32", "s_bfe_u32", "s_min_u32"}
+               "s_bitcmp1_b32", "s_bitcmp0_b32", "s_ashr_i32", "s_bfe_u32", "s_bfe_i32", "s_min_u32"}
 SCC_READERS = {"s_addc_u32", "s_subb_u32", "s_cselect_b32", "s_cselect_b64", "s_cbranch_scc0", "s_cbranch_scc1"}
 
 
@@ -115,7 +120,7 @@ class I(object):
                 o == "s_and_saveexec_b64" or any(isinstance(d, R) and d.kind == "exec" for d in self.dst))
 
     def is_mem(self):
-        return self.op in DS_OPS or self.op in VMEM_LD or self.op in VMEM_ST or self.op in SMEM
+        return self.op in DS_OPS or self.op in VMEM_LD or self.op in VMEM_ST or self.op in SMEM or self.op in VMEM_LDS
 
     # --- register sets (for the scheduler and the checks)
     def reads(self):
@@ -191,6 +196,13 @@ class I(object):
             return t
         if o in VMEM_LD:
             t = "%s %s, %s, %s" % (o, optext(d[0]), optext(s[0]), optext(s[1]))
+            if m.get("offset", 0):
+                t += " offset:%d" % m["offset"]
+            if m.get("cache"):
+                t += " " + m["cache"]
+            return t
+        if o in VMEM_LDS:
+            t = "%s %s, %s" % (o, optext(s[0]), optext(s[1]))
             if m.get("offset", 0):
                 t += " offset:%d" % m["offset"]
             if m.get("cache"):
@@ -272,12 +284,19 @@ def _latency(prod, cons, reg):
         return 3  # VALU write -> DPP read: 2 wait states
     if prod.op in VOP_TRANS and cons.is_valu():
         return 2  # trans result -> VALU: 1 wait state (gfx940)
-    if prod.is_valu() and reg[0] == "s" and cons.op in VMEM_LD | VMEM_ST:
+    if prod.is_valu() and reg[0] == "s" and cons.op in VMEM_LD | VMEM_ST | VMEM_LDS:
         return 6  # VALU writes SGPR -> VMEM reads it
+    if reg[0] == "m0" and cons.op in VMEM_LDS:
+        return 2  # SALU writes M0 -> LDS-DMA uses it: 1 wait state
     return 1
 
 
 SOFT_VALU_LATENCY = 1
+# Issue model measured on gfx950 with two waves per SIMD (profiles/r03_ubench_issue.txt): a scalar instruction placed between a
+# wave's vector instructions issues beside the partner wave's VALU work for free (up to one per two VALU instructions), a run of
+# scalar instructions costs ~6.5 cycles each.  MIX_POLICY: the list scheduler spreads the non-VALU instructions of a region
+# evenly between its VALU instructions instead of leaving them where their (short) dependency chains put them.
+MIX_POLICY = False
 
 
 def schedule_region(region):
@@ -328,8 +347,14 @@ def schedule_region(region):
     npred = [len(preds[j]) for j in range(n)]
     ready = [j for j in range(n) if npred[j] == 0]
     slot = 0
+    is_v = [ins.is_valu() for ins in region]
+    n_v = sum(is_v)
+    n_o = n - n_v
+    ratio = max(1, n_v // max(1, n_o)) if MIX_POLICY else 0   # VALU instructions between two others
+    run_v = 0
     while len(slot_of) < n:
         best = None
+        bestv = besto = None
         for j in ready:
             ok = all(slot - slot_of[i] >= d for i, d in preds[j].items())
             if not ok:
@@ -341,6 +366,19 @@ def schedule_region(region):
             key = (1 if at is not None and slot >= at * n else 0, 1 if relaxed else 0, prio[j] if at is None else 0, -j)
             if best is None or key > bestkey:
                 best, bestkey = j, key
+            if MIX_POLICY and not (at is not None and slot < at * n):
+                if is_v[j]:
+                    if bestv is None or key > bestvkey:
+                        bestv, bestvkey = j, key
+                elif besto is None or key > bestokey:
+                    besto, bestokey = j, key
+        if MIX_POLICY and bestv is not None and besto is not None:
+            # both kinds ready: a non-VALU instruction goes when it is due (every `ratio` VALU instructions) or was asked for
+            # at this point of the region
+            if bestokey[0] or run_v >= ratio:
+                best = besto
+            else:
+                best = bestv
         if best is None:
             out.append(I("s_nop", (), [0]))
             slot += 1
@@ -348,6 +386,7 @@ def schedule_region(region):
         ready.remove(best)
         slot_of[best] = slot
         out.append(region[best])
+        run_v = run_v + 1 if is_v[best] else 0
         slot += 1
         for j, _ in succs[best]:
             npred[j] -= 1

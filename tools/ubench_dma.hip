@@ -44,6 +44,21 @@ __global__ __launch_bounds__(64) void probe(const float* __restrict__ g, float* 
     for (int i = 0; i < 4; ++i) { out[lane * 4 + i] = v[i]; out[256 + lane * 4 + i] = u[i]; }
 }
 
+// does the instruction's immediate offset move the LDS destination as well as the global source?
+__global__ __launch_bounds__(64) void probe_off(const float* __restrict__ g, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_TOTAL];
+    const int lane = threadIdx.x;
+    const unsigned ldsb = (unsigned)(uintptr_t)lds;
+    for (int i = lane; i < 1024; i += 64) ((float*)lds)[i] = -1.f;
+    __syncthreads();
+    unsigned keep;
+    unsigned voff = lane * 16;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:512\n\ts_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)"
+                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(ldsb + 1024) : "memory");
+    __syncthreads();
+    for (int i = lane; i < 1024; i += 64) out[i] = ((float*)lds)[i];
+}
+
 // ---- part 2 ------------------------------------------------------------------------------------------------------------
 constexpr int PIECES = 12;          // 1 KiB pieces per workgroup-step
 constexpr int SLOT = PIECES * 1024;
@@ -147,6 +162,22 @@ int main() {
                 printf("probe lds_off %6u shift %d: err=%d  mismatches at lds_off: %d  at lds_off mod 64K: %d  (first %g %g)\n", off, shift,
                        (int)e, bad, bad_lo, r[0], r[256]);
             }
+    }
+    {
+        const int n = 4096;
+        std::vector<float> h(n);
+        for (int i = 0; i < n; ++i) h[i] = (float)i;
+        float *d, *o;
+        hipMalloc(&d, n * 4); hipMalloc(&o, 1024 * 4);
+        hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(probe_off, dim3(1), dim3(64), 0, 0, d, o);
+        std::vector<float> r(1024);
+        hipMemcpy(r.data(), o, 1024 * 4, hipMemcpyDeviceToHost);
+        int first = -1;
+        for (int i = 0; i < 1024; ++i) if (r[i] >= 0.f) { first = i; break; }
+        printf("offset:512 probe (M0 = lds + 1024 B): first written dword %d (256 = M0 only, 384 = M0 + offset), value there %g (128 = source + offset)\n",
+               first, first >= 0 ? r[first] : -1.f);
+        if (getenv("PROBE_ONLY")) return 0;
     }
     // ---- part 2
     const unsigned pitch_b = 1216 * 4, plane_b = 370000 * 4;
