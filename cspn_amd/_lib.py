@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
 ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -44,6 +44,9 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     c_int, c_size_t, vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
     lib.cspn_abi_version.restype = c_int
+    v = lib.cspn_abi_version()
+    if v != ABI_VERSION:   # (before any symbol lookup: a stale library must fail with this message, not an AttributeError)
+        raise CspnError("cspn_amd: ABI version mismatch: library %d, binding %d -- rebuild with `make -C cspn_amd/csrc`" % (v, ABI_VERSION))
     lib.cspn_last_error.restype = ctypes.c_char_p
     lib.cspn2d_workspace_bytes.restype = c_size_t
     lib.cspn2d_workspace_bytes.argtypes = [c_int] * 4
@@ -97,11 +100,12 @@ def load():
     lib.cspn3d_workspace_bytes_ex.argtypes = [c_int] * 7
     lib.cspn3d_forward_f32_algo.restype = c_int
     lib.cspn3d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 7 + [vp, c_size_t, vp]
+    lib.cspn3d_check_status.restype = c_int
+    lib.cspn3d_check_status.argtypes = [vp]
+    lib.cspn_debug_3d_mute_tile.restype = None
+    lib.cspn_debug_3d_mute_tile.argtypes = [c_int]
     lib.cspn_debug_3d_persistent_error.restype = c_int
     lib.cspn_debug_3d_persistent_error.argtypes = [vp] + [c_int] * 4
-    v = lib.cspn_abi_version()
-    if v != ABI_VERSION:
-        raise CspnError("cspn_amd: ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -22,6 +22,11 @@
 
 #include "cspn_common.h"
 
+#if (defined(P3_EXP_NOPOLL) || defined(P3_EXP_NOWAIT) || defined(P3_EXP_LANE_REMAP) || defined(P3_EXP_NT) || defined(P3_PRESLEEP)) && \
+    !defined(P3_EXPERIMENT_BUILD)
+#error "P3_EXP_* switch timing variants that give WRONG RESULTS: tools/build_p3var.sh defines P3_EXPERIMENT_BUILD for them"
+#endif
+
 namespace cspn {
 namespace {
 
@@ -47,6 +52,7 @@ struct Geo3 {
     int pitch, vw;           // columns between them are never inside a volume, so nothing flows across), vw = B pitch - 4
     int n_wg;                // workgroups launched (>= tz * ty * cx)
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
+    int mute;                // MUTE instantiation (test hook) only: the workgroup that never publishes
     long long gps, gbs;      // gate plane / batch stride in floats: [B][26][V] as given (V, 26 V) or folded planes [26][B][V] (B V, V)
 };
 
@@ -82,7 +88,11 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // the gate gradient multiplies with).
 // HASC: a constant term per voxel, H_{t+1} = c' + sum_k w'_k H_t(p + off_k): the folded form of the normalising / masked modes
 // (fold3d_kernel of cspn3d_stepwise.hip writes w' and c'); c' of the thread's eight voxels waits in LDS between the steps.
-template <bool ADJ, bool HASC>
+// The sticky status word of this device (host-mapped; set once by the host, read by the kernel only when it gives up)
+__device__ unsigned* g_status3 = nullptr;
+
+// MUTE (test hook): workgroup g.mute computes but never publishes, so that its neighbours run into the poll timeout
+template <bool ADJ, bool HASC, bool MUTE = false>
 __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
                                                                  const float* __restrict__ cprime, float* __restrict__ out,
                                                                  float* __restrict__ levels, float* __restrict__ scratch,
@@ -124,6 +134,13 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     bb = bf + (wr ? 1 : 0);
                     xx = wr ? xr - g.pitch : xr;
                 };
+                if (c > 0) {
+                    // the last step of the chunk before read the level buffers without a barrier behind it, and this prologue writes
+                    // level 0 into both: every wave must be through with those reads first (their results were consumed, so they
+                    // are complete; nothing else is in flight that the barrier would have to wait for)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
                 P3_CHUNK(0);
                 // ---- level 0 first (its loads are issued ahead of the gates' so that they return first): the thread's own eight
                 // voxels and its share of the 2504-voxel halo shell (outside the volume: 0, for good; outside the chunk window:
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         // values + the step tag): no wait for the stores, no flag, no barrier -- a reader polls the quad it needs
                         // until the tag is the step's.  A thread's eight values are the quads (0,1,2) (3,4,5) (6,7) of its row;
                         // boundary rows publish all 24, the others only the first and the last (the x faces).
-                        {
+                        if (!MUTE || wg != g.mute) {
                             float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
                             float4* rowq = mine + (lz * TY + ly) * XG + (lx >> 3);
                             const float tagf = __uint_as_float(target);
@@ -409,8 +426,13 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             src[j] = (unsigned)((((int)(target & 1) * g.n_wg + nbw) * NQ + quad) * 16);
                             dstp[j] = ((pz * LY + py) * LX + px) | (cnt << 14);
                         }
+                        // A neighbour that never publishes (it is not resident: the device is shared with work that holds CUs) must not
+                        // hang the kernel nor pass unnoticed: after SPIN_MAX polls (~0.5 s) the values that did not come are
+                        // taken as NaN -- the remaining steps carry them into this tile's voxels and on --, the device's sticky
+                        // status word is raised (cspn3d_check_status), and this workgroup waits only briefly from then on.
+                        const unsigned limit = s_bail ? 8u : SPIN_MAX;
                         unsigned tries = 0;
-                        bool pend = false;
+                        bool pend = false, lost = false;
 #pragma unroll
                         for (int j = 0; j < NSLOT; ++j) pend = pend || dstp[j] >= 0;
 #ifdef P3_PRESLEEP
@@ -434,26 +456,34 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             for (int j = 0; j < NSLOT; ++j) {
                                 if (dstp[j] < 0) continue;
 #ifdef P3_EXP_NOWAIT   // WRONG RESULTS, timing only: take whatever is there
-                                if (true) {
+                                const bool hit = true;
 #else
-                                if (__float_as_uint(qv[j].w) == target) {
+                                const bool hit = __float_as_uint(qv[j].w) == target;
 #endif
+                                if (hit || tries >= limit) {
                                     float* lp = nxt + (dstp[j] & 0x1fff);
                                     const int cnt = dstp[j] >> 14;
-                                    lp[0] = qv[j].x;
-                                    if (cnt >= 2) lp[1] = qv[j].y;
-                                    if (cnt == 3) lp[2] = qv[j].z;
+                                    const float bad = __uint_as_float(0x7fc00000u);
+                                    lp[0] = hit ? qv[j].x : bad;
+                                    if (cnt >= 2) lp[1] = hit ? qv[j].y : bad;
+                                    if (cnt == 3) lp[2] = hit ? qv[j].z : bad;
                                     dstp[j] = -1;
+                                    lost = lost || !hit;
                                 } else {
                                     pend = true;
                                 }
                             }
-                            if (pend && ++tries > SPIN_MAX) { *err = 2; s_bail = 1; break; }
+                            ++tries;
+                        }
+                        if (lost) {
+                            *err = 2;
+                            unsigned* st = g_status3;
+                            if (st) __hip_atomic_store(st, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            s_bail = 1;
                         }
                     }
                     __syncthreads();
                     P3_STAMP(4);
-                    if (s_bail) return;   // a neighbour never published (error word set): nothing below can complete
                 }
                 P3_CHUNK(3);
             }
@@ -461,17 +491,36 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// workgroups that can be resident at once: one per CU (the kernel takes a CU's whole register file), at most MAX_WG.  The
-// per-tile flags only work if every tile of a chunk is running.
+// per-device host state: what the residency needs (CU count), the chaining event of the plain launches, and the sticky status
+// word the kernel raises when a workgroup gives up -- one pinned, device-visible word per device, read by the host without a
+// synchronisation at the start of every later 3D call.  (This is the engine's only global mutable state.)
+struct Dev3 {
+    int wgs = 0;                      // workgroups that can be resident at once: one per CU (the kernel takes a CU's whole
+    hipEvent_t last = nullptr;        //   register file), at most MAX_WG
+    hipStream_t last_stream = nullptr;
+    unsigned* status_host = nullptr;  // host-mapped; its device address is in the device's copy of g_status3
+};
+std::mutex g_mu3;
+Dev3 g_dev3[64];
+int g_mute3 = -1;   // test hook (one-shot): the workgroup of the next launch that never publishes
+
+Dev3& dev3() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return g_dev3[dev];
+}
+
 int resident_wgs() {
-    static const int n = [] {
+    std::lock_guard<std::mutex> lock(g_mu3);
+    Dev3& d = dev3();
+    if (!d.wgs) {
         int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return MAX_WG;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return MAX_WG;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = MAX_WG;
         v *= WG_PER_CU;
-        return v < MAX_WG ? v : MAX_WG;
-    }();
-    return n;
+        d.wgs = v < MAX_WG ? v : MAX_WG;
+    }
+    return d.wgs;
 }
 
 Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
@@ -521,18 +570,35 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     g.gbs = cprime ? (long long)(total / B) : 26LL * (long long)(total / B);
     float* scratch = (float*)ws;
     unsigned* sync = (unsigned*)((char*)(scratch + 2 * total) + XBYTES);
-    // tags of an earlier call in this workspace must not validate: clear the published boundaries and the sync words
-    hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, XBYTES + 4096 * sizeof(unsigned), st);
+    // tags of an earlier call in this workspace must not validate: clear the published boundaries this launch indexes
+    // ([2][n_wg][NQ] quads) and the sync words
+    hipError_t e = hipMemsetAsync(scratch + 2 * total, 0, 2 * (size_t)g.n_wg * NQ * 16, st);
+    if (e == hipSuccess) e = hipMemsetAsync(sync, 0, 4096 * sizeof(unsigned), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     // Every workgroup waits for its neighbours' publications, so all of them must be resident at once, and two such kernels must
     // never be interleaved on the device (each would hold the CUs the other is waiting for).  Kernels of this process are kept
     // apart with an event: a launch waits for the previous persistent launch (whatever stream it went to) and records itself.
-    // Other work that happens to occupy CUs only delays the start.  CSPN_3D_COOP_LAUNCH=1 uses hipLaunchCooperativeKernel
-    // instead (the runtime then checks the residency too; ~23 us per launch, 0.905 -> 0.928 ms at config 5).  A stream that is
-    // being captured into a graph takes a plain launch: the replaying graph is the caller's to keep alone on the device.
+    // Other work that happens to occupy CUs only delays the start; if it never lets go, the waiting workgroups give up after
+    // SPIN_MAX polls (~0.5 s), take NaN for what did not come and raise the device's status word (persistent3d_take_status).
+    // CSPN_3D_COOP_LAUNCH=1 uses hipLaunchCooperativeKernel instead (the runtime then checks the residency too; ~23 us per
+    // launch, 0.905 -> 0.928 ms at config 5).  A stream that is being captured into a graph takes a plain launch: the replaying
+    // graph is the caller's to keep alone on the device.
+    std::lock_guard<std::mutex> lock(g_mu3);
+    Dev3& d = dev3();
+    if (!d.status_host) {
+        unsigned* devp = nullptr;
+        e = hipHostMalloc((void**)&d.status_host, 64, hipHostMallocMapped);
+        if (e == hipSuccess) { *d.status_host = 0; e = hipHostGetDevicePointer((void**)&devp, d.status_host, 0); }
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_status3), &devp, sizeof(devp));
+        if (e != hipSuccess) { set_error("status word of the persistent kernel: %s", hipGetErrorString(e)); d.status_host = nullptr; return (int)e; }
+    }
+    const int mute = g_mute3;
+    g_mute3 = -1;
+    g.mute = mute;
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
-                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, false> : (const void*)cspn3d_persistent_kernel<false, false>;
+                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, false>
+                   : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
     static const bool coop = getenv("CSPN_3D_COOP_LAUNCH") != nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
@@ -541,27 +607,30 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     } else if (capturing) {
         e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
     } else {
-        static std::mutex mu;
-        static hipEvent_t last[64] = {};
-        static hipStream_t last_stream[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!last[dev]) {
-            e = hipEventCreateWithFlags(&last[dev], hipEventDisableTiming);
+        if (!d.last) {
+            e = hipEventCreateWithFlags(&d.last, hipEventDisableTiming);
             if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); return (int)e; }
-        } else if (last_stream[dev] != st) {
-            e = hipStreamWaitEvent(st, last[dev], 0);
+        } else if (d.last_stream != st) {
+            e = hipStreamWaitEvent(st, d.last, 0);
             if (e != hipSuccess) { set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); return (int)e; }
         }
         e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
         if (e == hipSuccess) {
-            e = hipEventRecord(last[dev], st);
-            last_stream[dev] = st;
+            e = hipEventRecord(d.last, st);
+            d.last_stream = st;
         }
     }
     if (e != hipSuccess) { set_error("launch of cspn3d_persistent_kernel: %s", hipGetErrorString(e)); return (int)e; }
     return check_launch("cspn3d_persistent_kernel");
+}
+
+// the sticky status of this device's persistent launches: 0 = none gave up since the last call of this function
+// (reads a pinned host word the kernel writes with a system-scope store: no synchronisation; clears it)
+int persistent3d_take_status() {
+    std::lock_guard<std::mutex> lock(g_mu3);
+    Dev3& d = dev3();
+    if (!d.status_host) return 0;
+    return (int)__atomic_exchange_n(d.status_host, 0u, __ATOMIC_RELAXED);
 }
 
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
@@ -586,6 +655,12 @@ extern "C" int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int 
     const unsigned* p = (const unsigned*)((const char*)((const float*)ws + 2 * (size_t)B * D * H * W) + XBYTES) + MAX_WG + 64 * 9;
     if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)v;
+}
+
+// test hook: the workgroup of the NEXT plain (Paddle-contract) persistent launch that never publishes its boundary
+extern "C" void cspn_debug_3d_mute_tile(int wg) {
+    std::lock_guard<std::mutex> lock(g_mu3);
+    g_mute3 = wg;
 }
 
 }  // namespace cspn

@@ -94,7 +94,7 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
 }
 
 // ---- SURVEY 8f-2 experiment: guidance as 32 contiguous bytes per pixel, pre-sited by the producer
-int cspn2d_sited8_supported(int B, int H, int W, int n_iter) { return n_iter == 24 && (W % 2) == 0 && tsw2d_supported(B, H, W) ? 1 : 0; }
+int cspn2d_sited8_supported(int B, int H, int W, int n_iter) { return n_iter == 24 && tsw2d_supported(B, H, W) ? 1 : 0; }   // (W >= 256, W % 4 == 0)
 
 int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type, cspn_stream_t stream) {
     if (!guidance || !guidance_s8 || B <= 0 || H <= 0 || W <= 0 || (W % 2) != 0) { set_error("bad argument (W must be even)"); return CSPN_E_BADARG; }
@@ -169,6 +169,21 @@ int cspn2d_backward_history_f32(const float* guidance, const float* blur, const 
                               (hipStream_t)stream);
 }
 
+// a persistent 3D launch of an EARLIER call gave up (cspn3d_persistent.hip): report it once, through whichever 3D call comes next
+static int async_failure_of_earlier_call() {
+    if (persistent3d_take_status() == 0) return 0;
+    set_error("an earlier cspn3d call's persistent kernel gave up waiting for a neighbouring workgroup (not all of its workgroups were "
+              "resident: the device is shared with other work that holds compute units); that call's outputs are NaN-filled / invalid. "
+              "Re-run it, or request CSPN_ALGO3D_STEPWISE");
+    return CSPN_E_ASYNC;
+}
+
+int cspn3d_check_status(cspn_stream_t stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); return (int)e; }
+    return async_failure_of_earlier_call();
+}
+
 size_t cspn3d_workspace_bytes(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     return stepwise3d_workspace(B, D, H, W, n_iter);
@@ -191,6 +206,7 @@ int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* s
     if ((long long)B * D * H * W > 0x7fffffffLL / 27) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     if (algo < CSPN_ALGO3D_AUTO || algo > CSPN_ALGO3D_PERSISTENT) { set_error("unknown 3D algo %d", algo); return CSPN_E_BADARG; }
+    if (int e = async_failure_of_earlier_call()) return e;
     // misaligned tensors cannot take the 16-byte paths: they fold like the normalising modes (cspn3d_workspace_bytes())
     const bool aligned = ((((uintptr_t)gate | (uintptr_t)feat | (uintptr_t)out | (uintptr_t)ws) & 15u) == 0);
     size_t need = n_iter == 0 ? 0 : (aligned ? forward3d_workspace(B, D, H, W, n_iter, norm_type, sparse != nullptr)
@@ -219,6 +235,7 @@ int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_
         return CSPN_E_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (int e = async_failure_of_earlier_call()) return e;
     if (int e = check_common(gate, feat, grad_out, n_iter, norm_type, ws, ws_bytes, n_iter == 0 ? 0 : backward3d_workspace(B, D, H, W, n_iter))) return e;
     if (!grad_gate && !grad_feat) return 0;
     const size_t bytes = sizeof(float) * (size_t)B * D * H * W;

@@ -45,6 +45,10 @@ int persistent3d_forward_folded(const float* wf, const float* feat, float* out, 
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
                      int H, int W, int n_iter, void* ws, hipStream_t st);
 
+// sticky per-device status of the persistent launches: != 0 once after a launch gave up (a workgroup waited in vain for a
+// neighbour: not all workgroups resident); read without synchronisation from a pinned host word, cleared by the read
+int persistent3d_take_status();
+
 // ---- backward of the 3D op, Paddle contract only (cspn3d_backward.hip) ----
 size_t backward3d_workspace(int B, int D, int H, int W, int n_iter);
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W, int n_iter,

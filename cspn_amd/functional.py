@@ -176,7 +176,10 @@ def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs", alg
     if B == 0:
         return out
     with torch.cuda.device(g.device):
-        ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type], int(s is not None))
+        if any(t.data_ptr() % 16 for t in (g, h, out)):   # misaligned views take the folding path: the full workspace
+            ws_bytes = lib.cspn3d_workspace_bytes(B, D, H, W, int(n_iter))
+        else:
+            ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, int(n_iter), _lib.NORM_TYPES[norm_type], int(s is not None))
         ws = _workspace(ws_bytes, g.device)
         stream = torch.cuda.current_stream(g.device).cuda_stream
         rc = lib.cspn3d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
@@ -184,6 +187,17 @@ def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs", alg
                                          _lib.ALGOS_3D[algo], ws.data_ptr(), ws_bytes, stream)
     _lib.check(rc, "cspn3d_forward_f32")
     return (out, ws) if _return_ws else out
+
+
+def cspn3d_check_status(device=None):
+    """Synchronises the current stream of `device` and raises CspnError if a persistent 3D launch gave up on it (its outputs are
+    NaN-filled): the failure the C ABI can only report after the call has returned.  Every later cspn3d_* call raises it too
+    (once) without a synchronisation; call this where a result is about to be trusted without another 3D call in between."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        rc = lib.cspn3d_check_status(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "cspn3d_check_status")
 
 
 def cspn3d_backward(gate, feat, grad_out, n_iter=1, need_gate=True, need_feat=True):

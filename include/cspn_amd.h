@@ -11,9 +11,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (fp32, contiguous NCHW / NCDHW) valid on
  *     the current HIP device; the call only ENQUEUES work on `stream` and returns
- *     (no hipDeviceSynchronize, no allocation, no global mutable state: safe to
- *     call from several host threads, cf. nn.DataParallel at reference
- *     cspn_pytorch/eval.py:117);
+ *     (no hipDeviceSynchronize, no device allocation; safe to call from several
+ *     host threads, cf. nn.DataParallel at reference cspn_pytorch/eval.py:117).
+ *     The only state the library keeps between calls belongs to the persistent 3D
+ *     kernel: per device, the event that chains its launches and one pinned status
+ *     word (see cspn3d_check_status); everything else lives in the arguments;
  *   - inputs are never written; `out` must not alias an input;
  *   - return 0 on success, a negative CSPN_E_* code on argument errors, or a
  *     positive hipError_t; cspn_last_error() gives a thread-local message;
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 1
+#define CSPN_ABI_VERSION 2   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -48,7 +50,8 @@ enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2, CSPN_ALG
 enum {
     CSPN_E_BADARG = -1,   /* null pointer, non-positive size, unknown enum      */
     CSPN_E_WORKSPACE = -2, /* workspace too small or misaligned                  */
-    CSPN_E_UNSUPPORTED = -3 /* algo explicitly requested but shape not supported */
+    CSPN_E_UNSUPPORTED = -3, /* algo explicitly requested but shape not supported */
+    CSPN_E_ASYNC = -4      /* an EARLIER call failed on the device after it had returned (cspn3d_check_status) */
 };
 
 int cspn_abi_version(void);
@@ -79,7 +82,8 @@ int cspn2d_auto_algo(int B, int H, int W, int n_iter);
  * reference cspn.py:91-132 done by whoever writes the guidance (its natural home is the epilogue of the conv at
  * cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206,372); norm NONE: the centre-sited g_k(p).
  * cspn2d_guidance_to_sited8_f32 is that epilogue as a stand-alone kernel (tests, A/B timing).  Only where
- * cspn2d_sited8_supported(...) != 0 (passes of exactly 24 iterations, W >= 256, W % 4 == 0); no workspace. */
+ * cspn2d_sited8_supported(...) != 0 (passes of exactly 24 iterations, W >= 256, W % 4 == 0); no workspace.
+ * (SURVEY 8f-2 was measured with this entry point and closed: 9 % slower than the planar contract) */
 int cspn2d_sited8_supported(int B, int H, int W, int n_iter);
 int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type,
                                   cspn_stream_t stream);
@@ -130,6 +134,13 @@ int cspn3d_forward_f32(const float* gate, const float* feat, const float* sparse
  * over the gates (or the 27 folded planes) per step.  The persistent kernel needs all of its workgroups resident at once;
  * launches of one process are chained so that two of them never share the device: one process per GPU. */
 enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 2 };
+/* Failures that only show on the device.  The workgroups of the persistent kernel wait for each other; if some of them never get
+ * a compute unit (another process, a CU mask, a long kernel of another library on the device), the waiting ones give up after
+ * ~0.5 s, fill the voxels they own with NaN -- the call's `out` then never passes for a result -- and raise a sticky per-device
+ * status word.  The NEXT cspn3d_* call of the process on that device (forward or backward, any stream) finds it without a
+ * synchronisation, returns CSPN_E_ASYNC instead of enqueuing anything, and clears it.  cspn3d_check_status synchronises
+ * `stream` first, so it also reports the call just made: 0, CSPN_E_ASYNC or a hipError_t. */
+int cspn3d_check_status(cspn_stream_t stream);
 int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
                             void* workspace, size_t workspace_bytes, cspn_stream_t stream);

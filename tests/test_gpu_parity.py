@@ -285,6 +285,59 @@ def test_3d_persistent_vs_stepwise_and_oracle(B, D, H, W, N):
         assert_close(a.cpu().numpy(), cspn3d_oracle(g.cpu(), h.cpu(), None, N, "none"), "3d persistent")
 
 
+def test_3d_config5_full_size_persistent_vs_stepwise_every_voxel():
+    """BASELINE config 5 exactly (4 x 32x160x608, 12 steps): the geometry bench.py --workload vol3d times -- 15 chunks cut from
+    the row of four volumes standing side by side -- against one launch per step, on every voxel.  Parity unpinned (the Paddle
+    op's source is not in the reference tree): the two HIP paths hold each other, the oracle holds both on sub-volumes."""
+    B, D, H, W, N = 4, 32, 160, 608, 12
+    gen = torch.Generator(device=DEV).manual_seed(55)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=DEV)
+    g /= g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device=DEV) * 80
+    a, ws = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent", _return_ws=True)
+    b = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="stepwise")
+    cspn_amd.cspn3d_check_status()
+    assert cspn_amd.load().cspn_debug_3d_persistent_error(ws.data_ptr(), B, D, H, W) == 0
+    assert torch.isfinite(a).all()
+    d = (a - b).abs()
+    tol = 1e-6 * float(b.abs().max()) + 1e-5 * b.abs()
+    assert bool((d <= tol).all()), float(d.max())
+    del a, b, d, tol
+    sub = (slice(1, 2), slice(None), slice(0, 8), slice(40, 64), slice(544, 608))   # a corner of volume 1 incl. its last columns
+    gs, hs = g[sub].contiguous(), h[sub[0], :, sub[2], sub[3], sub[4]].contiguous()
+    o = cspn_amd.cspn3d_forward(gs, hs, None, N, "none", algo="persistent")
+    assert_close(o.cpu().numpy(), cspn3d_oracle(gs.cpu(), hs.cpu(), None, N, "none"), "3d persistent sub-volume")
+
+
+def test_3d_persistent_timeout_surfaces_as_an_error():
+    """a workgroup whose neighbour never publishes (test hook: one tile computes but keeps quiet -- what a tile that never got a
+    compute unit looks like to the others) must not hang, must not return something that passes for a result, and must be
+    reported: NaN in the output, CSPN_E_ASYNC from cspn3d_check_status and -- once -- from the next cspn3d_* call, after which the
+    engine works again."""
+    B, D, H, W, N = 1, 16, 24, 128, 6
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=DEV)
+    g /= g.sum(1, keepdim=True)
+    h = torch.rand(B, 1, D, H, W, generator=gen, device=DEV)
+    good = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent")
+    cspn_amd.cspn3d_check_status()
+    lib = cspn_amd.load()
+    lib.cspn_debug_3d_mute_tile(1)
+    bad = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent")   # returns at once: the failure happens on the device
+    with pytest.raises(cspn_amd.CspnError, match="gave up"):
+        cspn_amd.cspn3d_check_status()
+    assert bool(torch.isnan(bad).any())
+    cspn_amd.cspn3d_check_status()                                             # reported once, then cleared
+    lib.cspn_debug_3d_mute_tile(0)
+    cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent")
+    torch.cuda.synchronize()
+    with pytest.raises(cspn_amd.CspnError, match="gave up"):                   # the NEXT call finds it without a synchronisation
+        cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent")
+    again = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent")
+    cspn_amd.cspn3d_check_status()
+    assert torch.equal(again, good)
+
+
 def test_paddle_style_affinity_propagate():
     gen = torch.Generator().manual_seed(8)
     x = torch.rand(2, 3, 5, 12, 16, generator=gen)  # C=3 channels share the gates (README.md:56)
