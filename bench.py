@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS) + ["vol3d"])
     ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch-per-gpu images on every rank.  strong: --global-batch images (BASELINE config 3: "
+                         "batch 64 sharded over the GPUs of the node, the scatter of reference cspn_pytorch/eval.py:115-118) cut into "
+                         "contiguous per-rank chunks, rank r owns images [r G / N, (r + 1) G / N)")
+    ap.add_argument("--global-batch", type=int, default=64)
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,8 +287,15 @@ def main():
     if a.workload == "vol3d":
         return run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu)
     H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
-    B = a.batch_per_gpu
-    g, h, s = synth(B, H, W, scale, sparse, dev, first=rank * B)
+    if a.scaling == "strong":
+        from cspn_amd.dist import shard_range
+        first, last = shard_range(a.global_batch, rank, world)
+        B = last - first
+        if B <= 0:
+            raise SystemExit("--scaling strong: --global-batch %d leaves rank %d of %d without an image" % (a.global_batch, rank, world))
+    else:
+        B, first = a.batch_per_gpu, rank * a.batch_per_gpu
+    g, h, s = synth(B, H, W, scale, sparse, dev, first=first)
     algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
     algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
     norm = _lib.NORM_TYPES[a.norm_type]
@@ -353,9 +365,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms_avg = float(t[0]), float(t[1])
 
+    total_images = B * world
+    if dist is not None and a.scaling == "strong":
+        nb = torch.tensor([float(B)], device="cpu" if shared_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        total_images = int(nb.item())
     if rank == 0:
         px = B * H * W
-        total_mpix_iters = world * px * n_iter * a.steps / 1e6
+        total_mpix_iters = total_images * H * W * n_iter * a.steps / 1e6
         value = total_mpix_iters / elapsed
         bytes_per_px = 44 if sparse else 40  # guidance 32 + blur 4 (+ sparse 4) + out 4
         alg_bytes = px * bytes_per_px  # per launch (one forward = all n_iter iterations), per GPU
@@ -370,7 +387,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (randn affinity, uniform depth*%g; image i of the global batch from torch.Generator().manual_seed(1000+i) "
@@ -378,15 +395,18 @@ def main():
             "prewarm_s": round(prewarm_s, 3), "prewarm_launches": prewarm_launches,
             "parity_checked": parity,
             "config": {
-                "workload": "%s, batch %d per GPU" % (desc, B),
-                "B_per_gpu": B, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
+                "workload": ("%s, batch %d per GPU" % (desc, B)) if a.scaling == "weak"
+                            else "%s, global batch %d sharded over %d GPU(s) (%d images on rank 0)" % (desc, total_images, world, B),
+                "B_per_gpu": B, "global_batch": total_images, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
                 "algo": algo_name, "guidance_layout": a.layout, "parallelism": "batch-sharded x%d, no data-path collective" % world
                                           + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup plans its own "
-                           "row stream in LDS, nothing else runs inside the timed region)") if algo_name == "fused" and W >= 256 and n_iter == 24
+                "kernel": ("cspn2d_tsw3_kernel (gfx950 assembly main loop, LDS-DMA row slots; ONE launch per forward: every workgroup "
+                           "plans its own row stream in LDS, nothing else runs inside the timed region)"
+                           if not os.environ.get("CSPN_TSW_V2") else
+                           "cspn2d_tsw_kernel (round-2 assembly main loop, CSPN_TSW_V2=1)") if algo_name == "fused" and W >= 256 and n_iter == 24
                           else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
                           else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
                 "achieved": round(achieved, 1),

@@ -102,6 +102,8 @@ def load():
     lib.cspn3d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 7 + [vp, c_size_t, vp]
     lib.cspn3d_check_status.restype = c_int
     lib.cspn3d_check_status.argtypes = [vp]
+    lib.cspn_debug_tsw_loop.restype = None
+    lib.cspn_debug_tsw_loop.argtypes = [c_int]
     lib.cspn_debug_3d_mute_tile.restype = None
     lib.cspn_debug_3d_mute_tile.argtypes = [c_int]
     lib.cspn_debug_3d_persistent_error.restype = c_int

@@ -103,3 +103,20 @@ def test_bench_two_ranks_launch_path():
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
     assert res["parity_checked"]["ok"] and res["parity_checked"]["all_ranks_ok"]
     assert res["value"] > 0 and res["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_strong_scaling_shards_the_global_batch():
+    """--scaling strong (BASELINE config 3's shape: ONE global batch sharded over the ranks, the scatter of reference
+    cspn_pytorch/eval.py:115-118): 7 images over 2 ranks = 4 + 3, the reported value counts every image once"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--scaling", "strong", "--global-batch", "7", "--prewarm-s", "0.1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["config"]["global_batch"] == 7 and res["config"]["B_per_gpu"] == 4
+    assert res["parity_checked"]["ok"] and res["parity_checked"]["all_ranks_ok"]
+    mpix = 7 * 304 * 1216 * 24 * 5 / 1e6
+    assert abs(res["value"] * res["ms_per_step"] * 5 / 1e3 - mpix) <= 1e-3 * mpix

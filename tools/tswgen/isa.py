@@ -31,13 +31,15 @@ class R(object):
 
     def regs(self):
         if self.kind in ("vcc", "exec"):
-            return [(self.kind, 0), (self.kind, 1)]
+            return [(self.kind, 0), (self.kind, 1)] if self.n == 2 else [(self.kind, self.i)]
         if self.kind == "m0":
             return [("m0", 0)]
         return [(self.kind, self.i + k) for k in range(self.n)]
 
     def text(self):
-        if self.kind in ("vcc", "exec", "m0"):
+        if self.kind in ("vcc", "exec") and self.n == 1:
+            t = self.kind + ("_lo", "_hi")[self.i]
+        elif self.kind in ("vcc", "exec", "m0"):
             t = self.kind
         elif self.n == 1:
             t = "%s%d" % (self.kind, self.i)

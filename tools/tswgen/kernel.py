@@ -88,6 +88,7 @@ S_PFB = S(54, 2)             # cfg pf: base address of the row being prefetched
 S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16 (one band per workgroup)
 S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
 S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(45), S(33), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
+S_AM = [S(56), S(57), S(58), S(59)]   # per ring slot: -1 if it holds a real row, 0 for a separator / padding row (round 3)
 S_EL, S_ER = S(38, 2), S(40, 2)
 S_ENF = S(44)                   # event: the entering row's descriptor dword 3 (flags)
 S_EO = S(48, 2)                 # event: the retiring row's descriptor dwords 2:3 (boff, flags | lo | hi)
@@ -280,6 +281,7 @@ class Gen(object):
         self.e("s_andn2_b32", S_ACT, [S_ACT, 1 << j])
         self.e("s_bitcmp1_b32", (), [S_ENF, F_ACTIVE])
         self.e("s_cselect_b32", T[2], [1 << j, 0])
+        self.e("s_cselect_b32", S_AM[j], [-1, 0])
         self.e("s_or_b32", S_ACT, [S_ACT, T[2]])
         self.e("s_cmp_lg_u32", (), [S_ACT, 15])           # vcc != 0 <=> some slot holds a separator / padding row:
         self.e("s_cselect_b64", VCC, [1, 0])              # the per-slot checks of the event-free steps are one branch each
@@ -312,8 +314,14 @@ class Gen(object):
 
     def act_check(self, j, vq):
         """a slot holding a separator / padding row is pinned to zero (0 x NaN from a neighbour must not leak into it).
-        Modelled as one pseudo instruction so that the scheduler may move independent work across it; the zeroing stub
-        lives out of line."""
+        Round 3: the completed value is ANDed with the slot's 0 / -1 mask, in the steps that have such a row resident only (the
+        step body exists twice: see step()).  The round-2 form -- one never-taken branch per slot in every step, a stub that
+        zeroes -- cost 0.03 ms of a 0.29 ms forward: ~8 taken branches per step in the ~26 % of steps with such a row (ring
+        fill / drain, image boundaries), profiles/r03_perf_notes.md."""
+        if self.cfg.get("act_and", True):
+            for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
+                self.e("v_and_b32", vq[k], [S_AM[j], vq[k]])
+            return
         stub, back = self.p.newlabel("actz"), self.p.newlabel("actb")
         from .isa import I
         exp = [I("s_cbranch_vccnz", (), [stub]), I("label", (), [back])]
@@ -359,7 +367,11 @@ class Gen(object):
         if not skip_above1:
             self.push_above(1, v0, D_TAIL, ACC(p, 1), init=WT(1, 8))
 
-    def step(self, c):
+    def step(self, c, slow=False):
+        """Round 3: two bodies per counter -- the fast one assumes that all four slots hold real rows (vcc == 0) and carries no
+        per-slot checks; `slow` (out of line, entered by one branch at the top of the fast body) pins slots that hold a
+        separator / padding row to zero."""
+        act_fast = self.cfg.get("act_and", True) and not self.elastic and "noact" not in self.ab
         p = c & 1
         N1 = [ACC(p, j) for j in range(4)]
         N2 = [ACC(p ^ 1, j) for j in range(4)]
@@ -389,7 +401,12 @@ class Gen(object):
             self.e("s_bitcmp1_b32", (), [S_WV, 2])
             self.e("s_cbranch_scc0" if cook_hi else "s_cbranch_scc1", (), [lab])
             return lab
-        self.p.label(".LS%d_%%=" % c)
+        if slow:
+            self.p.label(".LSs%d_%%=" % c)
+        else:
+            self.p.label(".LS%d_%%=" % c)
+            if act_fast:
+                self.e("s_cbranch_vccnz", (), [".LSs%d_%%=" % c])
         # an event makes this wave the slowest of the step while the wave it shares its SIMD with has slack: let it issue first
         prio = self.cfg.get("prio", 1) if ev is not None else 0
         if prio:
@@ -477,7 +494,7 @@ class Gen(object):
                 self.inject(j, vq, hn, copy=not (slim and j > 0))
                 if slim and j > 0:
                     vq = hn
-            elif "noact" not in self.ab:
+            elif "noact" not in self.ab and (slow or not act_fast):
                 self.act_check(j, vq)
             if self.hist and ev != j:
                 self.hist_store(j, vq)
@@ -518,8 +535,8 @@ class Gen(object):
         self.trace_flush(c, cook)
         self.e("s_sub_u32", S_TAU, [S_TAU, 1])           # S_TAU counts the remaining steps down; the borrow ends the loop
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
-        if c == LV - 1:
-            self.e("s_branch", (), [".LS0_%="])
+        if slow or c == LV - 1:
+            self.e("s_branch", (), [".LS%d_%%=" % ((c + 1) % LV)])
 
     # ---------------------------------------------------------------------------------- cfg elastic: tags instead of the barrier
     def tag_reads(self, c, p, ev, stub=False):
@@ -855,6 +872,8 @@ class Gen(object):
             self.mov(q[1], 0)
         e("s_mov_b32", S_TAU, [S_LAST])
         e("s_mov_b32", S_ACT, [0])
+        for j in range(4):
+            e("s_mov_b32", S_AM[j], [0])
         e("s_mov_b64", VCC, [1])
         e("s_and_b32", T[2], [S_LOHI, 0xffff])
         e("s_lshr_b32", T[3], [S_LOHI, 16])
@@ -1106,6 +1125,9 @@ class Gen(object):
             self.step(c)
         self.p.label(".Lexit_%=")
         self.e("s_branch", (), [".Lend_%="])
+        if self.cfg.get("act_and", True) and not self.elastic and "noact" not in self.ab:
+            for c in range(LV):
+                self.step(c, slow=True)
         for st in self.estubs:
             self.emit_tag_stub(*st)
         if self.elastic:

@@ -22,7 +22,9 @@ What is new (cspn.py:85-144 normalisation, :76 centre term, :81 mask -- "cooking
     DMA-issuing wave leaves "output byte offset | owned | active" in a per-slot header for the event that injects the row.
 Variants: norm x (sparse | hin | none).  History / adjoint / sparse+hin variants stay on kernel.py's loop.
 """
-from .isa import Prog, V, S, EXEC, VCC, M0, I, schedule, check_hazards, expand_pseudos
+from .isa import Prog, V, S, R, EXEC, VCC, M0, I, schedule, check_hazards, expand_pseudos
+
+R_EXEC_LO, R_EXEC_HI = R("exec", 0, 1), R("exec", 1, 1)
 
 NW, NSLOT, LV = 8, 4, 24
 PADF, PADB = 36, 64          # inactive descriptor rows before / after a workgroup's stream
@@ -404,6 +406,9 @@ class Gen(object):
             if not cook_top:
                 self.cook_math()
             self.cook_writes()
+        if "maskhack" in self.ab:   # timing experiment (WRONG RESULTS): 12 of 64 lanes switched off for the chain -- does the
+            self.e("s_mov_b32", R_EXEC_LO, [0xffffffc0])   # forward get faster when the VALU moves less (power), at equal issue?
+            self.e("s_mov_b32", R_EXEC_HI, [0x03ffffff])
         # received boundary rows
         self.shift(BQ, D_BQ)
         self.push_below(3, BQ, D_BQ, N1[3])
@@ -438,6 +443,8 @@ class Gen(object):
                 self.push_self(j, vq, tq, N2[j])
             if j < 3:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
+        if "maskhack" in self.ab:
+            self.e("s_mov_b64", EXEC, [-1])
         if cookr:
             # the raw values of the task this wave cooks in the next step (group g + 1); nobody waits for them before the barrier
             self.e("s_add_u32", T[2], [S_TG, S_CK4])
