@@ -35,6 +35,9 @@ namespace {
 #ifndef P3_XG
 #define P3_XG 8
 #endif
+#ifndef P3_BACKOFF
+#define P3_BACKOFF 0   // s_sleep units (64 cycles) between two polls of quads that were not there yet
+#endif
 constexpr int XG = P3_XG, XGS = XG == 8 ? 3 : 2, WG_PER_CU = 8 / XG;
 static_assert(XG == 8 || XG == 4, "x-groups per tile row");
 constexpr int TZ = 8, TY = 8, TX = 8 * XG;       // 8 consecutive x per thread
@@ -474,6 +477,11 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 }
                             }
                             ++tries;
+#if P3_BACKOFF > 0
+                            // a quad that was not there yet will take a good part of a memory-side round trip to appear: polling at
+                            // full speed only multiplies the polled bytes (1.4 GB per forward at config 5, profiles/pmc_traffic.json)
+                            if (pend) __builtin_amdgcn_s_sleep(P3_BACKOFF);
+#endif
                         }
                         if (lost) {
                             *err = 2;

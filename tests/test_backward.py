@@ -12,6 +12,7 @@ import torch
 from helpers import make_inputs
 from oracle.backward import cspn2d_backward_oracle
 
+GFLOOR = 5e-6
 GTOL = 2e-4  # relative to max|grad|: 1e-4 forward tolerance with headroom for the longer accumulation chains
 NORMS = {0: "8sum", 1: "8sum_abs"}
 
@@ -21,6 +22,18 @@ def _golden():
     for n in sorted({k.split("/")[0] for k in z.files}):
         c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")}
         yield n, c
+
+
+def _check(a, b, what=""):
+    """gradient parity, element-wise: |a - b| <= GFLOOR * max|ref| + GTOL * |ref| (the form of the forward's
+    helpers.assert_close_tight: dL/dguidance carries 1 / sum|g| tails, so a max-norm check alone leaves everything small
+    unchecked) AND max-norm <= GTOL.  GFLOOR = 5e-6: with the forward's 1e-6 the 3 x 70 x 512 '8sum_abs' case exceeds the bound
+    2.1x at elements below 1 % of max|grad| (max-norm error 3.5e-6) -- fp32 cancellation in
+    dG_k = dw_k / S - sign(G_k) sum_j dw_j G_j / S^2 summed over 24 levels, an absolute error of ~2e-6 max|grad| wherever the two
+    terms nearly cancel; the float64 oracle has none of it, the reference's own fp32 autograd has the same."""
+    from helpers import assert_close
+    assert_close(a, b, what, rtol=GTOL, atol_frac=GFLOOR)
+    return True
 
 
 def _err(a, b):
@@ -46,8 +59,8 @@ def test_hip_backward_vs_reference_autograd_goldens():
         t = {k: torch.from_numpy(v).cuda() for k, v in c.items() if k != "meta"}
         gg, gh = cspn_amd.cspn2d_backward(t["guidance"], t["blur"], t.get("sparse"), t["grad_out"], N, NORMS[norm])
         torch.cuda.synchronize()
-        assert _err(gg.cpu().numpy(), c["grad_guidance"]) <= GTOL, name
-        assert _err(gh.cpu().numpy(), c["grad_blur"]) <= GTOL, name
+        assert _check(gg.cpu().numpy(), c["grad_guidance"]), name
+        assert _check(gh.cpu().numpy(), c["grad_blur"]), name
 
 
 @pytest.mark.gpu
@@ -63,12 +76,12 @@ def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
     m = cspn_amd.Affinity_Propagate(N, 3, norm)
     out = m(gd, hd, None if s is None else s.cuda())
     out.backward(go.cuda())
-    assert _err(gd.grad.cpu().numpy(), rgg) <= GTOL
-    assert _err(hd.grad.cpu().numpy(), rgh) <= GTOL
+    assert _check(gd.grad.cpu().numpy(), rgg)
+    assert _check(hd.grad.cpu().numpy(), rgh)
     # only one input needs a gradient: the other output is skipped
     hd2 = h.cuda().requires_grad_(True)
     m(g.cuda(), hd2, None if s is None else s.cuda()).backward(go.cuda())
-    assert _err(hd2.grad.cpu().numpy(), rgh) <= GTOL
+    assert _check(hd2.grad.cpu().numpy(), rgh)
 
 
 @pytest.mark.gpu
@@ -95,7 +108,7 @@ def test_training_mode_history_matches_recompute_path(norm, sp):
     o = m(g1, h1, sd)
     assert o.grad_fn is not None and len(o.grad_fn.saved_tensors) == 4 and o.grad_fn.saved_tensors[3] is not None
     o.backward(go)
-    assert _err(g1.grad.cpu().numpy(), rgg) <= GTOL and _err(h1.grad.cpu().numpy(), rgh) <= GTOL
+    assert _check(g1.grad.cpu().numpy(), rgg) and _check(h1.grad.cpu().numpy(), rgh)
     m.keep_history = False
     g2, h2 = g.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
     m(g2, h2, sd).backward(go)
@@ -147,5 +160,5 @@ def test_forward_and_backward_vs_stock_torch_autograd_at_full_width():
     out = cspn_amd.Affinity_Propagate(N, 3, "8sum")(g1, h1, s.cuda())
     out.backward(go)
     assert _err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-4
-    assert _err(g1.grad.cpu().numpy(), g0.grad.cpu().numpy()) <= GTOL
-    assert _err(h1.grad.cpu().numpy(), h0.grad.cpu().numpy()) <= GTOL
+    assert _check(g1.grad.cpu().numpy(), g0.grad.cpu().numpy())
+    assert _check(h1.grad.cpu().numpy(), h0.grad.cpu().numpy())

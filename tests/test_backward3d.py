@@ -11,6 +11,7 @@ import torch
 from oracle import cspn3d_oracle
 from oracle.backward import OFF3, cspn3d_backward_oracle, cspn3d_forward_levels
 
+GFLOOR = 5e-6
 GTOL = 2e-4   # relative to max|grad|, as for the 2D backward
 
 
@@ -36,6 +37,18 @@ def _torch_forward(g, h, n_iter):
             acc = acc + g[:, k] * pad[:, 1 + dz:1 + dz + D, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
         x = acc
     return x[:, None]
+
+
+def _check(a, b, what=""):
+    """gradient parity, element-wise: |a - b| <= GFLOOR * max|ref| + GTOL * |ref| (the form of the forward's
+    helpers.assert_close_tight: dL/dguidance carries 1 / sum|g| tails, so a max-norm check alone leaves everything small
+    unchecked) AND max-norm <= GTOL.  GFLOOR = 5e-6: with the forward's 1e-6 the 3 x 70 x 512 '8sum_abs' case exceeds the bound
+    2.1x at elements below 1 % of max|grad| (max-norm error 3.5e-6) -- fp32 cancellation in
+    dG_k = dw_k / S - sign(G_k) sum_j dw_j G_j / S^2 summed over 24 levels, an absolute error of ~2e-6 max|grad| wherever the two
+    terms nearly cancel; the float64 oracle has none of it, the reference's own fp32 autograd has the same."""
+    from helpers import assert_close
+    assert_close(a, b, what, rtol=GTOL, atol_frac=GFLOOR)
+    return True
 
 
 def _err(a, b):
@@ -82,7 +95,7 @@ def test_hip_3d_backward_vs_oracle(B, D, H, W, N, signed):
     g, h, go = _inputs(B, D, H, W, seed=11 + N, signed=signed)
     dG, dF = cspn3d_backward_oracle(g.numpy(), h.numpy(), go.numpy(), N)
     gg, gf = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N)
-    assert _err(gg.cpu().numpy(), dG) <= GTOL and _err(gf.cpu().numpy(), dF) <= GTOL
+    assert _check(gg.cpu().numpy(), dG) and _check(gf.cpu().numpy(), dF)
     # either output alone
     gg1, none = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N, need_feat=False)
     none2, gf1 = cspn_amd.cspn3d_backward(g.cuda(), h.cuda(), go.cuda(), N, need_gate=False)
@@ -108,7 +121,7 @@ def test_affinity_propagate_mirror_is_differentiable_like_the_paddle_op():
     y.backward(go.cuda())
     assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
     for got_g, got_h in ((g1.grad, h1.grad), (g2.grad, h2.grad)):
-        assert _err(got_g.cpu().numpy(), gt.grad.numpy()) <= GTOL and _err(got_h.cpu().numpy(), ht.grad.numpy()) <= GTOL
+        assert _check(got_g.cpu().numpy(), gt.grad.numpy()) and _check(got_h.cpu().numpy(), ht.grad.numpy())
     # 2D flavour of the op (8 gates), two input channels sharing the gates (README.md:56)
     gen = torch.Generator().manual_seed(9)
     g8 = torch.rand(2, 8, 12, 20, generator=gen); g8 = g8 / g8.sum(1, keepdim=True)
@@ -129,7 +142,7 @@ def test_affinity_propagate_mirror_is_differentiable_like_the_paddle_op():
             v = sum(gt2[:, k] * pad[:, 1 + DY[k]:1 + DY[k] + 12, 1 + DX[k]:1 + DX[k] + 20] for k in range(8))
         acc.append(v)
     torch.stack(acc, 1).sum().backward()
-    assert _err(gd.grad.cpu().numpy(), gt2.grad.numpy()) <= GTOL and _err(xd.grad.cpu().numpy(), xt2.grad.numpy()) <= GTOL
+    assert _check(gd.grad.cpu().numpy(), gt2.grad.numpy()) and _check(xd.grad.cpu().numpy(), xt2.grad.numpy())
 
 
 @pytest.mark.gpu
