@@ -23,12 +23,18 @@ for case in range(int(os.environ.get("FUZZ_CASES", "40"))):
         g = g.abs() / (g.abs().sum(1, keepdim=True) + 0.2)
     h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
     s = (torch.rand(B, 1, H, W, generator=gen, device="cuda") < 0.02).float() * (h + 0.1) if sp else None
-    a = cspn_amd.cspn2d_forward(g, h, s, N, norm, "fused")
     b = cspn_amd.cspn2d_forward(g, h, s, N, norm, "stepwise")
-    assert torch.equal(torch.isnan(a), torch.isnan(b)), ("2D nan", B, H, W, norm, sp, N)
-    err = float(((a - b).abs().nan_to_num()).max() / b.abs().nan_to_num().max().clamp_min(1e-30))
-    worst2 = max(worst2, err)
-    assert err <= 1e-5, ("2D", B, H, W, norm, sp, N, err)
+    lib = cspn_amd.load()
+    for loop in (2, 3):   # both assembly loops, whatever the dispatch rule would pick (FUZZ_LOOPS=0: the rule)
+        lib.cspn_debug_tsw_loop(loop if os.environ.get("FUZZ_LOOPS", "1") != "0" else 0)
+        try:
+            a = cspn_amd.cspn2d_forward(g, h, s, N, norm, "fused")
+        finally:
+            lib.cspn_debug_tsw_loop(0)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), ("2D nan", loop, B, H, W, norm, sp, N)
+        err = float(((a - b).abs().nan_to_num()).max() / b.abs().nan_to_num().max().clamp_min(1e-30))
+        worst2 = max(worst2, err)
+        assert err <= 1e-5, ("2D", loop, B, H, W, norm, sp, N, err)
     if B * H * W <= 120000:
         r = cspn2d_oracle(g.cpu(), h.cpu(), None if s is None else s.cpu(), N, norm)
         e2 = float(np.nanmax(np.abs(a.cpu().numpy() - r)) / np.nanmax(np.abs(r)))

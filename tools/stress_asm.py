@@ -13,7 +13,10 @@ import cspn_amd  # noqa: E402
 def main():
     torch.manual_seed(0)
     bad = 0
-    for (B, H, W, sp) in [(8, 304, 1216, True), (64, 304, 1216, False), (16, 228, 304, True), (3, 57, 260, False)]:
+    lib = cspn_amd.load()
+    for (B, H, W, sp, loop) in [(8, 304, 1216, True, 3), (64, 304, 1216, False, 3), (64, 304, 1216, True, 2), (16, 228, 304, True, 3),
+                                (3, 57, 260, False, 3), (16, 228, 304, True, 2)]:
+        lib.cspn_debug_tsw_loop(loop)   # 2: round-2 loop, 3: round-3 loop (LDS-DMA: a missing wait / barrier would flicker)
         gen = torch.Generator(device="cuda").manual_seed(B + W)
         g = torch.randn(B, 8, H, W, generator=gen, device="cuda")
         h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
@@ -31,7 +34,8 @@ def main():
                 gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
                 flick += int(not torch.equal(gg, gg0)) + int(not torch.equal(gh, gh0))
         torch.cuda.synchronize()
-        print("B%d %dx%d sparse=%s: asm vs compiled %.2e, non-identical repeats %d" % (B, H, W, sp, d, flick), flush=True)
+        lib.cspn_debug_tsw_loop(0)
+        print("B%d %dx%d sparse=%s loop %d: asm vs compiled %.2e, non-identical repeats %d" % (B, H, W, sp, loop, d, flick), flush=True)
         bad += flick + int(d > 1e-5)
     print("STRESS", "OK" if bad == 0 else "FAILED")
     return bad
