@@ -36,7 +36,7 @@ def test_emulated_asm_loop_vs_oracle(B, H, W, n_wg, norm, sparse, hin, zp):
 def test_emulated_sited8_input_variant(norm, sparse):
     """cfg s8 (SURVEY 8f-2 experiment): the guidance arrives pre-sited and pair-interleaved, four aligned 16-byte loads per task"""
     os.chdir(ROOT)
-    err, nanmis, _, ref = run_case(2, 15, 304, 4, norm, sparse, False, seed=11, zero_patch=(norm != 2), verbose=False, s8=True)
+    err, nanmis, _, ref = run_case(2, 15, 304, 4, norm, sparse, False, seed=11, zero_patch=(norm != 2), verbose=False, s8=True)   # (stub form of the inactive-row checks)
     assert nanmis == 0 and err <= 1e-4
 
 
