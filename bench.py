@@ -9,7 +9,8 @@ A "step" is one pass of the hot path (all n_iter propagation iterations, one C-A
 over this rank's batch of synthetic affinity + depth tensors, already resident in HBM.
 Workload (config.workload): BASELINE.json configs[2] -- 2D CSPN 3x3, 24 iterations, KITTI
 304x1216 -- at 64 images PER GPU (the full config-3 batch fits one MI355X: 1.0 GB of 288 GB);
-the batch shards embarrassingly, so N>1 is weak scaling with no data-path collective.  The only
+the batch shards embarrassingly, so N>1 is weak scaling with no data-path collective (--scaling strong --global-batch 64 shards
+ONE batch over the ranks instead: BASELINE config 3 as written, 64 / N images per GPU).  The only
 collective is the one-time RCCL broadcast of a backbone-sized weight buffer (outside the timed
 region, reported as broadcast_ms).  Data: image i of the global batch is seeded by 1000 + i on the
 CPU.  Before the counted warm-up the launch runs untimed for --prewarm-s seconds

@@ -92,7 +92,7 @@ S_GEOM = S(14)   # input: ybits | first band << 8 | last band << 9
 S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16
 S_P04 = S(12)    # input: byte offset of the band's first column inside an image row
 S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
-S_TAU, S_ACT, S_QB, S_TG, S_CFLAGS = S(45), S(33), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
+S_TAU, S_QB, S_TG, S_CFLAGS = S(45), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
 # S_TG: LDS address of the descriptor of stream row 4 g, g = step number div 3 (the cooking group entering now)
 S_EL, S_ER = S(38, 2), S(40, 2)
 S_TABB = S(37)                  # LDS address of descriptor row 0 (table base + PADF rows)
@@ -197,10 +197,6 @@ class Gen(object):
             return
         self.e("ds_read_b128", dst, [V_RINGE], offset=ev * SLOT + q * 1024, **m)
 
-    def zero_quad(self, q):
-        for k in (0, 3, 2, 1):  # the DPP sources first (VALU -> DPP distance)
-            self.mov(q[k], 0)
-
     def wrap_slot(self, reg, add):
         """reg <- reg + add, wrapped into the pool of row slots"""
         self.e("s_add_u32", reg, [reg, add])
@@ -264,7 +260,6 @@ class Gen(object):
         self.e("s_cmp_lg_u32", (), [T[2], -1])            # vcc != 0 <=> some slot holds a separator / padding row: those
         self.e("s_cselect_b64", VCC, [1, 0])              # steps run the body that pins such slots to zero
         if j == 3:
-            self.e("s_add_i32", S_QB, [S_QB, 32])
             self.wrap_slot(S_EGRP, 8 * SLOT)               # the next burst's rows are 32 further down the stream: 32 mod 12 = 8 slots
             self.wrap_hdr(S_EHDR, 32)
 
@@ -358,6 +353,13 @@ class Gen(object):
         prio = self.cfg.get("prio", 1) if ev is not None else 0
         if prio:
             self.e("raw", (), ["s_setprio %d" % prio])
+        yp = self.cfg.get("youngprio", 0)   # experiment: the younger wave of a SIMD (wv >= 4) leads for the first part of the chain
+        if yp:
+            lab = self.p.newlabel("old")
+            self.e("s_bitcmp1_b32", (), [S_WV, 2])
+            self.e("s_cbranch_scc0", (), [lab])
+            self.e("raw", (), ["s_setprio 2"])
+            self.p.label(lab)
         self.probe(0)
         partial = not self.cfg.get("trace", False)
         # slim events: the H0 quad read for the row entering slot ev is, one step later, the "row above" of the row entering
@@ -433,6 +435,8 @@ class Gen(object):
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=0, at=0.0)
             if j == 0:
                 break  # slot 0's own pushes: tail(), at the top of the next step
+            if yp and j == yp:
+                self.e("raw", (), ["s_setprio %d" % prio])
             self.shift(vq, tq)
             self.push_below(j - 1, vq, tq, N1[j - 1])
             if ev == j:
