@@ -1,12 +1,18 @@
 """tools/tswgen/census.py -- static instruction census of the generated loop, per step variant (ring counter c):
-python -m tools.tswgen.census [cfg-dict]   e.g.  python -m tools.tswgen.census "dict(sparse=True)" """
+python -m tools.tswgen.census [cfg-dict]   e.g.  python -m tools.tswgen.census "dict(sparse=True)"
+(a cfg with loop=3 counts the round-3 loop, tools/tswgen/kernel3.py) """
 import sys
 
 from . import kernel as K
 
 
 def census(cfg):
-    p = K.build(cfg)
+    cfg = dict(cfg)
+    if cfg.pop("loop", 2) == 3:
+        from . import kernel3
+        p = kernel3.build(cfg)
+    else:
+        p = K.build(cfg)
     blocks, cur = {}, "prologue"
     for ins in p.ins:
         if ins.op == "label" and ins.src[0].startswith(".LS"):

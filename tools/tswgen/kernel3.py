@@ -120,6 +120,9 @@ GB, BX, AX = S(2, 2), S(6, 2), S(48, 2)   # row bases of the DMA being issued (g
 # requested at steps 3g - 8 (jj 0), 3g - 7 (jj 1), 3g - 6 (jj 2, 3): their slots were vacated by the events of steps 3g - 9 ..
 # 3g - 7.  The requesting wave waits for its row at the top of step 3g - 3 (DMA_WAIT counters), the barrier of that step
 # publishes it.
+# (Counter 15 shares its SIMD with the event wave at counter 3 -- waves w and w + 4 share one, their counters differ by 12;
+# requesting at 21 instead, cfg dma_issue / dma_wait, keeps every SIMD to one heavy wave-step: measured, no difference, the
+# scalar instructions of a request co-issue with the partner's FMAs; profiles/r03_ablations_raw.txt r3n.)
 DMA_ISSUE = {6: (2, 2), 15: (3, 2), 10: (0, 3), 20: (1, 3)}
 DMA_WAIT = (9, 18, 15, 0)
 
@@ -136,6 +139,8 @@ class Gen(object):
         self.stubs = []
         self.cstubs = []
         self.ab = set(cfg.get("ablate", ()))  # timing experiments only (results are wrong)
+        self.dma_issue = cfg.get("dma_issue", DMA_ISSUE)   # (A/B builds of other request schedules)
+        self.dma_wait = cfg.get("dma_wait", DMA_WAIT)
 
     # ---------------------------------------------------------------------------------- small helpers
     def e(self, op, dst=(), src=(), **m):
@@ -336,9 +341,9 @@ class Gen(object):
         nocook = "nocook" in self.ab
         ph = c % 3
         cookr, cookw = (ph == 1 and not nocook), (ph == 2 and not nocook)
-        dma = None if nocook else DMA_ISSUE.get(c)                     # (jj, groups ahead) of the row this wave requests now
-        dma_next = None if nocook else DMA_ISSUE.get((c + 1) % LV)    # ... at the top of the next step: fetch its descriptor
-        dma_wait = c in DMA_WAIT and not nocook
+        dma = None if nocook else self.dma_issue.get(c)                     # (jj, groups ahead) of the row this wave requests now
+        dma_next = None if nocook else self.dma_issue.get((c + 1) % LV)    # ... at the top of the next step: fetch its descriptor
+        dma_wait = c in self.dma_wait and not nocook
         act_fast = self.cfg.get("act_fast", True) and "noact" not in self.ab
         cook_top = self.cfg.get("cook_top", True)
         tau3 = self.cfg.get("tau3", True)
@@ -916,8 +921,8 @@ class Gen(object):
         # waves whose first counter is a requesting one (step 0: g = 0) need that row's descriptor now
         for w in range(NW):
             c0 = (LV - 3 * w) % LV
-            if c0 in DMA_ISSUE and "nocook" not in self.ab:
-                jj, dg = DMA_ISSUE[c0]
+            if c0 in self.dma_issue and "nocook" not in self.ab:
+                jj, dg = self.dma_issue[c0]
                 lab = self.p.newlabel("nofirst")
                 e("s_cmp_lg_u32", (), [S_WV, w])
                 e("s_cbranch_scc1", (), [lab])
