@@ -23,7 +23,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the boxes export it,
+# a shell that does not gets it here, before the HIP runtime is loaded
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

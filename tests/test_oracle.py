@@ -23,6 +23,19 @@ def test_oracle_matches_golden(golden):
         assert err <= 1e-5, (name, err)  # oracle is pinned an order tighter than the product gate
 
 
+@pytest.mark.parametrize("channel_sum", ["conv3d", "sum"])
+def test_torch_ops_baseline_matches_golden(golden, channel_sum):
+    """the torch-op restatement that stands in for "the reference on this GPU" in tools/bench_torch_ops_baseline.py computes what
+    the unmodified reference computed (NaN where it has NaN)"""
+    from tools.torch_ops_baseline import affinity_propagate_torch_ops
+    for name, c in golden.items():
+        B, H, W, N, norm = [int(v) for v in c["meta"]]
+        sp = torch.from_numpy(c["sparse"]) if "sparse" in c else None
+        out = affinity_propagate_torch_ops(torch.from_numpy(c["guidance"]), torch.from_numpy(c["blur"]), sp, N, NORMS[norm], channel_sum).numpy()
+        assert np.array_equal(np.isnan(out), np.isnan(c["out"])), name
+        assert rel_err(out, c["out"]) <= 1e-5, (name, rel_err(out, c["out"]))
+
+
 @pytest.mark.skipif(not ref_harness.available(), reason="/root/reference not present (GPU box)")
 @pytest.mark.parametrize("B,H,W,N,norm,sp", [(1, 228, 304, 12, "8sum", False), (2, 31, 45, 24, "8sum", True),
                                              (1, 64, 200, 24, "8sum_abs", True)])
