@@ -94,6 +94,21 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // The sticky status word of this device (host-mapped; set once by the host, read by the kernel only when it gives up)
 __device__ unsigned* g_status3 = nullptr;
 
+// Gate quads of the NEXT chunk parked in the LDS the level buffers leave free (round 3): during the first NPRE / 2 steps of a
+// chunk each thread requests both quads of one gate plane of its voxels in the next chunk by LDS-DMA (global_load_lds_dwordx4:
+// no destination register -- the 208 gate registers leave none; M0 carries the LDS address, all 160 KB are reachable on gfx950,
+// profiles/r03_ubench_dma.txt), while HBM is otherwise idle; the next prologue reads them back with ds_read_b128 and requests
+// 52 - NPRE quads from memory instead of 52.  A wave reads only what it requested itself (its vmcnt wait makes the data visible
+// to it: no barrier), laid out [quad][wave][lane] so that one request fills 1 KiB.
+template <bool ADJ, bool HASC>
+struct Pre3 { static constexpr int N = ADJ ? 0 : (XG == 8 ? (HASC ? 10 : 12) : 12); };
+
+__device__ __forceinline__ void lds_dma16(unsigned byte_off, const float* base, unsigned lds_dst) {   // lds_dst: wave-uniform
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+
 // MUTE (test hook): workgroup g.mute computes but never publishes, so that its neighbours run into the poll timeout
 template <bool ADJ, bool HASC, bool MUTE = false>
 __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
@@ -102,6 +117,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                  unsigned* __restrict__ sync, Geo3 g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * LTILE];
     __shared__ __attribute__((aligned(16))) float4 s_c[HASC ? 2 * NTP : 1];   // c' of the thread's two quads, [quad][thread]
+    constexpr int NPRE = Pre3<ADJ, HASC>::N;
+    __shared__ __attribute__((aligned(16))) float4 s_pre[NPRE ? NPRE * NTP : 1];   // parked gate quads, [quad][thread] (addressed by hand)
     __shared__ int s_bail;
     unsigned* err = sync + MAX_WG + 64 * 9;  // [1] (the words in front of it belonged to the flag exchange of the first version)
 #ifdef P3_TRACE
@@ -119,6 +136,34 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool have_tile = wg < tiles;
     const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
     if (tid == 0) s_bail = 0;
+    // byte offsets of a thread's two gate quads in chunk cc (what the chunk prologue below calls voff0 / voff1)
+    auto gate_offs = [&](int cc, int tc, unsigned& v0, unsigned& v1) {
+        const int x0n = cc * g.S - g.halo + ix * TX;
+        const int bfn = __builtin_amdgcn_readfirstlane(x0n > 0 ? x0n / g.pitch : 0);
+        const int lxn = (tc & (XG - 1)) * 8, lyn = (tc >> XGS) & 7, lzn = tc >> (XGS + 3);
+        const int zn = iz * TZ + lzn, yn = iy * TY + lyn;
+        const int xr0 = x0n + lxn - bfn * g.pitch, xr1 = xr0 + 4;
+        const int bq0 = bfn + (xr0 >= g.pitch ? 1 : 0), xq0n = xr0 >= g.pitch ? xr0 - g.pitch : xr0;
+        const int bq1 = bfn + (xr1 >= g.pitch ? 1 : 0), xq1n = xr1 >= g.pitch ? xr1 - g.pitch : xr1;
+        const bool inzy = zn < g.D && yn < g.H;
+        const int rown = (zn * g.H + yn) * g.W;
+        v0 = inzy && xq0n >= 0 && xq0n + 3 < g.W && bq0 < g.B ? (unsigned)(bq0 * (int)g.gbs + rown + xq0n) * 4u : 0u;
+        v1 = inzy && xq1n >= 0 && xq1n + 3 < g.W && bq1 < g.B ? (unsigned)(bq1 * (int)g.gbs + rown + xq1n) * 4u : 0u;
+    };
+    auto park_gate = [&](int cc, int k, int tc) {   // both quads of gate plane k of chunk cc -> s_pre[2k], s_pre[2k + 1]
+        unsigned v0, v1;
+        gate_offs(cc, tc, v0, v1);
+        const float* gk = gate + (size_t)k * g.gps;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(s_pre) + (unsigned)((2 * k * NTP + (tc & ~63)) * 16));
+        lds_dma16(v0, gk, dst);
+        lds_dma16(v1, gk, dst + NTP * 16);
+    };
+    if (NPRE && have_tile && g.nchunk > 0) {   // the first chunk's share, so that every prologue finds its parked quads
+        int tc = tid;
+        asm volatile("" : "+v"(tc));
+#pragma unroll 1
+        for (int k = 0; k < NPRE / 2; ++k) park_gate(0, k, tc);
+    }
     {
         for (int c = 0; c < g.nchunk; ++c) {
             const unsigned round = (unsigned)c;
@@ -144,6 +189,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
+                if (NPRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's parked gate quads have landed
                 P3_CHUNK(0);
                 // ---- level 0 first (its loads are issued ahead of the gates' so that they return first): the thread's own eight
                 // voxels and its share of the 2504-voxel halo shell (outside the volume: 0, for good; outside the chunk window:
@@ -227,13 +273,19 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(r0_), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(r1_), "s"(gk) : "memory");
 #else
+                    if (2 * k < NPRE) {   // parked during the chunk before (chunk 0: in front of the loop)
+                        const unsigned pa = lds_addr(s_pre) + (unsigned)tc * 16u + (unsigned)(2 * k * NTP * 16), pb = pa + NTP * 16;
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(w[k][0]) : "v"(pa) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(w[k][1]) : "v"(pb) : "memory");
+                    } else {
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][0]) : "v"(voff0), "s"(gk) : "memory");
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(w[k][1]) : "v"(voff1), "s"(gk) : "memory");
+                    }
 #endif
                     }
                 }
                 {   // level 0 into both LDS buffers once ITS loads are back (52 gate loads may still be in flight)
-                    asm volatile("s_waitcnt vmcnt(52)" : "+v"(f0), "+v"(f1) : : "memory");
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(52 - NPRE) : "memory");
                     if (HASC) {   // (outside the volume c' = 0: such voxels keep the value 0)
                         asm volatile("" : "+v"(cq0), "+v"(cq1));
                         const v4f zero = {0.f, 0.f, 0.f, 0.f};
@@ -279,7 +331,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 // the gates are back; outside the volume they are zero (such voxels keep the value 0)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]) : : "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]) : : "memory");
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
                     if (k) asm volatile("" : "+v"(w[k][0]), "+v"(w[k][1]));
@@ -314,6 +366,10 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float* cur = lds + ((it - 1) & 1) * LTILE;
                     float* nxt = lds + (it & 1) * LTILE;
                     P3_STAMP(0);
+                    if (NPRE && c + 1 < g.nchunk) {   // one gate plane of the next chunk per step (all of them if there are few steps)
+#pragma unroll 1
+                        for (int k = it - 1; k < NPRE / 2; k += g.n_iter) park_gate(c + 1, k, tid_);
+                    }
                     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (HASC) {
                         const unsigned ca = lds_addr(s_c) + (unsigned)tid_ * 16u;
