@@ -618,6 +618,10 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
 
 constexpr size_t XBYTES = 2 * (size_t)MAX_WG * NQ * 16;   // published tile boundaries, two level parities
 
+// One size for the whole Paddle-contract call, whichever path ends up taking it (the size query has no algo argument and the
+// same workspace must serve `algo` 1): two value volumes -- the ping-pong of the per-step path, which also takes the calls
+// the persistent kernel declines (residency, n_iter); the persistent kernel itself does not touch them --, then the published
+// tile boundaries and the sync / error words.
 size_t persistent3d_workspace(int B, int D, int H, int W) {
     return 2 * (size_t)B * D * H * W * sizeof(float) + XBYTES + 4096 * sizeof(unsigned);
 }
