@@ -186,8 +186,10 @@ __device__ __forceinline__ float dpp_wshl1(float v) {   // across the wave: lane
 
 // RL = lanes per image row inside a wave: 16 (a wave = 4 rows x 16 groups, a block = 16 rows x 64 columns) or 64 (a wave = one
 // row of 64 groups = 1 KB per load, a block = 4 rows x 256 columns, blocks numbered so that vertical neighbours share an XCD)
-template <int RL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
+// NB = level buffers: NB - 1 levels are in flight while one is being multiplied.  2 at three waves per SIMD is what ships: 3 buffers
+// need 224 registers (two waves per SIMD) and ran 1.53 ms against 1.41 (profiles/r03_backward_final_variants.txt)
+template <int RL, int NB>
+__device__ __forceinline__ void bwd_final4_body(const float* __restrict__ g, const float* __restrict__ blur,
                                                           const float* __restrict__ sparse, const float* __restrict__ hh,
                                                           const float* __restrict__ ah, const float* __restrict__ a0p,
                                                           const float* __restrict__ gout, float* __restrict__ gg,
@@ -227,6 +229,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     // One level = A_{t+1} times the three rows of H_t around the thread's row.  All ten loads of a level (A, three H groups, the
     // columns beside the group for the end lanes of a 16-lane row) are issued together and one level AHEAD of the arithmetic, so
     // that a wave always has a level in flight (issued one by one behind their uses, every load paid a full memory round trip).
+    // RL == 16: a wave holds four consecutive image rows (16 lanes each), so the H row above / below a lane's row IS the own row of
+    // the lane 16 further down / up: only the wave's first / last row of lanes load theirs, the others take it from that lane with
+    // ds_bpermute_b32 once the level has arrived -- 1 + 1 + 2 x 1/4 quad loads per lane and level instead of 4 (the pass was
+    // running the L1 request path at ~3/4 of its rate: 4 KB of requests per wave and level at 64 B/clk, twelve waves per CU).
+    constexpr bool VSHARE = RL == 16;
+    const int lrow = lane >> 4;   // (RL == 16) the lane's row inside the wave
     struct Lvl { float4 a, r[3]; float e0[3], e5[3]; };
     // t = 0: H_0 = blur (image order), A_1 = adjoint level N-2;  t = 1..N-2: histories;  t = N-1: A_N = dL/dout (image order)
     auto fetch = [&](int t, Lvl& L, bool first, bool last) {
@@ -239,7 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
 #pragma unroll
         for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1
             const int yy = y + 1 - d;
-            const bool rowin = valid && yy >= 0 && yy < H;
+            bool rowin = valid && yy >= 0 && yy < H;
+            if (VSHARE && ((d == 0 && lrow < 3) || (d == 2 && lrow > 0))) rowin = false;   // comes from the lane 16 down / up
             const float* row = ht + base + (size_t)(rowin ? yy : 0) * W;
             L.r[d] = z4;
             L.e0[d] = L.e5[d] = 0.f;
@@ -249,7 +258,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
             if (gx == RL - 1 && rowin && x + 4 < W) L.e5[d] = row[x + 4];
         }
     };
-    auto compute = [&](const Lvl& L, bool first, bool last) {
+    auto from_lane = [&](float v, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+    };
+    auto compute = [&](Lvl& L, bool first, bool last) {
+        if (VSHARE) {   // rows above / below from the neighbouring rows of lanes (an invalid lane holds zeros: outside the image)
+            const int dn = (lane + 16) & 63, up = (lane - 16) & 63;
+            const float4 o = L.r[1];
+            const float4 fd = make_float4(from_lane(o.x, dn), from_lane(o.y, dn), from_lane(o.z, dn), from_lane(o.w, dn));
+            const float4 fu = make_float4(from_lane(o.x, up), from_lane(o.y, up), from_lane(o.z, up), from_lane(o.w, up));
+            const float e0d = from_lane(L.e0[1], dn), e5d = from_lane(L.e5[1], dn);
+            const float e0u = from_lane(L.e0[1], up), e5u = from_lane(L.e5[1], up);
+            if (lrow < 3) { L.r[0] = fd; L.e0[0] = e0d; L.e5[0] = e5d; }
+            if (lrow > 0) { L.r[2] = fu; L.e0[2] = e0u; L.e5[2] = e5u; }
+        }
         const bool a_reg_order = !last, h_reg_order = !first;
         float a[4];
         if (a_reg_order) { a[0] = L.a.x; a[1] = L.a.z; a[2] = L.a.w; a[3] = L.a.y; }   // (c0,c3,c1,c2)
@@ -286,24 +308,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
             }
         }
     };
-    static_assert(N % 2 == 0 && N >= 4, "the level loop alternates two buffers");
+    static_assert(N % NB == 0 && N / NB >= 2, "the level loop rotates NB buffers");
     {
-        Lvl LA, LB;
-        fetch(0, LA, true, false);
-        fetch(1, LB, false, false);
-        compute(LA, true, false);
-        fetch(2, LA, false, false);
-        compute(LB, false, false);
-#pragma unroll 1
-        for (int t = 2; t < N - 2; t += 2) {   // LA holds level t
-            fetch(t + 1, LB, false, false);
-            compute(LA, false, false);
-            fetch(t + 2, LA, false, false);
-            compute(LB, false, false);
+        Lvl L[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fetch(i, L[i], i == 0, false);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {   // levels 0 .. NB - 1
+            compute(L[i], i == 0, false);
+            fetch(NB + i, L[i], false, NB + i == N - 1);
         }
-        fetch(N - 1, LB, false, true);
-        compute(LA, false, false);
-        compute(LB, false, true);
+#pragma unroll 1
+        for (int t = NB; t < N - NB; t += NB) {   // L[i] holds level t + i
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                compute(L[i], false, false);
+                fetch(t + NB + i, L[i], false, t + NB + i == N - 1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) compute(L[i], false, i == NB - 1);   // levels N - NB .. N - 1
     }
     if (!valid) return;
     // ---- epilogue: the chain through the fold, the normalisation and the neighbour-sited gather (see the file header)
@@ -407,6 +431,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     }
 }
 
+template <int RL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
+                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
+                                                          const float* __restrict__ ah, const float* __restrict__ a0p,
+                                                          const float* __restrict__ gout, float* __restrict__ gg,
+                                                          float* __restrict__ gb, int B, int H, int W, int norm) {
+    bwd_final4_body<RL, 2>(g, blur, sparse, hh, ah, a0p, gout, gg, gb, B, H, W, norm);
+}
+
 }  // namespace
 
 // final pass of the assembly-sweep backward; CSPN_BWD_FINAL_RL=64 selects the one-row-per-wave mapping (A/B)
@@ -417,8 +450,8 @@ static void launch_final4(const float* g, const float* blur, const float* sparse
         const int nbx = (W / 4 + 63) / 64, nby = (H + 3) / 4, ntile = nbx * nby * B, per = (ntile + 7) / 8;
         hipLaunchKernelGGL(bwd_final4_kernel<64>, dim3(per * 8), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm);
     } else {
-        hipLaunchKernelGGL(bwd_final4_kernel<16>, dim3((W / 4 + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, g, blur, sparse, hh, ah, a0,
-                           gout, gg, gb, B, H, W, norm);
+        const dim3 grid((W / 4 + 15) / 16, (H + 15) / 16, B);
+        hipLaunchKernelGGL(bwd_final4_kernel<16>, grid, dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm);
     }
 }
 
