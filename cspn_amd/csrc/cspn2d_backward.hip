@@ -186,6 +186,113 @@ __device__ __forceinline__ float dpp_wshl1(float v) {   // across the wave: lane
 
 // RL = lanes per image row inside a wave: 16 (a wave = 4 rows x 16 groups, a block = 16 rows x 64 columns) or 64 (a wave = one
 // row of 64 groups = 1 KB per load, a block = 4 rows x 256 columns, blocks numbered so that vertical neighbours share an XCD)
+// ---- the end of the final pass for one register-order group of 4 columns (b, y, x .. x + 3): from dW'_k and dC through the fold,
+// the normalisation and the neighbour-sited gather to dL/dguidance and dL/dblur_depth (see the file header)
+__device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse,
+                                              const float* __restrict__ a0p, float* __restrict__ gg, float* __restrict__ gb, int b, int y,
+                                              int x, size_t idx, size_t HW, int H, int W, int norm, const float (&dW)[8][4],
+                                              const float (&dC)[4]) {
+    // ---- epilogue: the chain through the fold, the normalisation and the neighbour-sited gather (see the file header)
+    const float4 h0q = *reinterpret_cast<const float4*>(blur + idx);
+    const float h0[4] = {h0q.x, h0q.y, h0q.z, h0q.w};
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sparse) {
+        const float4 sq = *reinterpret_cast<const float4*>(sparse + idx);
+        m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w);
+    }
+    const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
+    const float a0[4] = {a0q.x, a0q.y, a0q.z, a0q.w};
+    const float* gbp = g + (size_t)b * 8 * HW;
+    float* ggp = gg ? gg + (size_t)b * 8 * HW : nullptr;
+    if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
+        if (gb) *reinterpret_cast<float4*>(gb + idx) = make_float4(a0[0] + dC[0] * m[0], a0[1] + dC[1] * m[1], a0[2] + dC[2] * m[2],
+                                                                    a0[3] + dC[3] * m[3]);
+        if (ggp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
+                    make_float4((1.f - m[0]) * dW[k][0], (1.f - m[1]) * dW[k][1], (1.f - m[2]) * dW[k][2], (1.f - m[3]) * dW[k][3]);
+        }
+        return;
+    }
+    // Two passes over the eight planes (the second re-reads its 4-column runs from cache) instead of keeping G, the raw values
+    // and dL/dw of all planes in registers: the kernel has to stay at 4+ waves per SIMD to hide its loads.
+    // G_k(p) = g~_k(p + off_k): a run of four columns of plane k in row y + dy_k starting at x + dx_k, zero outside the image
+    auto run = [&](int k, float (&v)[4]) -> bool {
+        const int yy = y + dy2(k), xs = x + dx2(k);
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (yy < 0 || yy >= H) return false;
+        const float* src = gbp + k * HW + (size_t)yy * W;
+        if (xs >= 0 && xs + 3 < W) {
+            const float4 q = ld4u(src + xs);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xs + i >= 0 && xs + i < W) v[i] = src[xs + i];
+        }
+        return true;
+    };
+    float om[4], ch[4], S[4] = {0.f, 0.f, 0.f, 0.f}, T1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v[4];
+        run(k, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+            S[i] += fabsf(v[i]);
+            gs[i] += G;
+            T1[i] = fmaf(om[i] * (dW[k][i] - ch[i]), G, T1[i]);
+        }
+    }
+    float rS[4], t2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rS[i] = 1.f / S[i]; t2[i] = T1[i] / (S[i] * S[i]); }
+    if (gb) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] / S[i]) + m[i]);
+        *reinterpret_cast<float4*>(gb + idx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (ggp) {
+        // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ys = y - dy2(k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xq = x + i - dx2(k);
+                if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v[4];
+            if (!run(k, v)) continue;  // the zero padding is a constant
+            const int yy = y + dy2(k), xs = x + dx2(k);
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+                const float sg = G > 0.f ? 1.f : (G < 0.f ? -1.f : 0.f);
+                float r = om[i] * (dW[k][i] - ch[i]) * rS[i] - sg * t2[i];
+                if (norm == CSPN_NORM_8SUM_ABS) r *= v[i] > 0.f ? 1.f : (v[i] < 0.f ? -1.f : 0.f);
+                d[i] = r;
+            }
+            float* dst = ggp + k * HW + (size_t)yy * W;   // g_k(p + off_k) is read by pixel p only
+            if (xs >= 0 && xs + 3 < W) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xs + i >= 0 && xs + i < W) dst[xs + i] = d[i];
+            }
+        }
+    }
+}
+
 // NB = level buffers: NB - 1 levels are in flight while one is being multiplied.  2 at three waves per SIMD is what ships: 3 buffers
 // need 224 registers (two waves per SIMD) and ran 1.53 ms against 1.41 (profiles/r03_backward_final_variants.txt)
 template <int RL, int NB>
@@ -330,105 +437,188 @@ __device__ __forceinline__ void bwd_final4_body(const float* __restrict__ g, con
         for (int i = 0; i < NB; ++i) compute(L[i], false, i == NB - 1);   // levels N - NB .. N - 1
     }
     if (!valid) return;
-    // ---- epilogue: the chain through the fold, the normalisation and the neighbour-sited gather (see the file header)
-    const float4 h0q = *reinterpret_cast<const float4*>(blur + idx);
-    const float h0[4] = {h0q.x, h0q.y, h0q.z, h0q.w};
-    float m[4] = {0.f, 0.f, 0.f, 0.f};
-    if (sparse) {
-        const float4 sq = *reinterpret_cast<const float4*>(sparse + idx);
-        m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w);
-    }
-    const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
-    const float a0[4] = {a0q.x, a0q.y, a0q.z, a0q.w};
-    const float* gbp = g + (size_t)b * 8 * HW;
-    float* ggp = gg ? gg + (size_t)b * 8 * HW : nullptr;
-    if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
-        if (gb) *reinterpret_cast<float4*>(gb + idx) = make_float4(a0[0] + dC[0] * m[0], a0[1] + dC[1] * m[1], a0[2] + dC[2] * m[2],
-                                                                    a0[3] + dC[3] * m[3]);
-        if (ggp) {
+    bwd_epilogue4(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dW, dC);
+}
+
+// ---- final pass from CHECKPOINTS (round 3): the sweeps keep every fourth level only ----------------------------------------
+// The forward sweep stores H_4, H_8 .. H_20, the adjoint sweep A_20, A_16 .. A_4 (generator option hist_every; H_0 = blur and
+// A_24 = dL/dout are inputs): 10 level planes through HBM instead of 46.  This pass recomputes the three levels in between,
+// tile by tile: a block of 512 threads owns a REGION of 32 rows x 16 groups of 4 columns and produces the TILE that is left
+// 4 pixels inside it (24 x 56); thread = one group (a wave = 4 region rows of 16 lanes, so the columns beside a group come
+// from the neighbouring lane of the 16-lane DPP row, the rows above / below through LDS).  Per segment s = 0, 4 .. 20:
+//   H_{s+1..s+3} = c' + sum_k w'_k shift_k(H)            (pull form; valid one pixel further inside the region per step)
+//   for t = s+3 .. s:  dW'_k += A_{t+1} H_t(. + off_k), dC += A_{t+1};  A_t(q) = sum_k (w'_k A_{t+1})(q - off_k)
+// the adjoint step in PUSH form, so that both recurrences use the thread's own, centre-sited w'_k(p) -- 32 registers loaded
+// once per tile, no coefficient traffic per step: p sends P_k = w'_k(p) A_{t+1}(p) to q = p + off_k; what goes to the row
+// below / above is summed over its three columns first (T_dn / T_up, one quad each through LDS), the in-row part stays in
+// the lanes.  c' is not stored: c' = H_0 (1 - sum_k w'_k) for the normalising modes (any sparse sign), m H_0 for norm NONE.
+// Outside the image everything is exactly 0, as in the forward's zero padding.
+#if (defined(BWD_EXP_NOEPI) || defined(BWD_EXP_NOLOOP) || defined(BWD_EXP_NOBAR)) && !defined(BWD_EXPERIMENT_BUILD)
+#error "BWD_EXP_* switch timing variants that give WRONG RESULTS: tools/build_bwdvar.sh defines BWD_EXPERIMENT_BUILD for them"
+#endif
+constexpr int CK = 4, CK_GR = 16, CK_TG = CK_GR - 2, NCKP = 24 / CK - 1;   // NCKP: level planes a sweep keeps
+
+__device__ __forceinline__ float4 reg_to_img(float4 q) { return make_float4(q.x, q.z, q.w, q.y); }   // (c0,c3,c1,c2) -> (c0..c3)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt 0), i.e. for the next
+// segment's checkpoints that are meant to arrive under this segment's arithmetic
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// CK_ROWS = region rows: 48 (one block of 768 threads per CU, three waves per SIMD, the next segment's checkpoints prefetched) or
+// 32 (two blocks of 512 threads per CU, four waves per SIMD = 128 registers: no prefetch, the other block covers the loads)
+template <int CK_ROWS>
+__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(CK_ROWS == 32 ? 4 : 3, CK_ROWS == 32 ? 4 : 3))) void bwd_final_ck_kernel(
+    const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
+    const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
+    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
+    constexpr int N = 24, NSEG = N / CK, CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    __shared__ __attribute__((aligned(16))) float4 sH[CK][CK_NT];      // H_s .. H_{s+3} of the region (image order inside a quad)
+    __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
+    const int tid = threadIdx.x, gx = tid & (CK_GR - 1), ry = tid >> 4;
+    const int W4 = W >> 2, b = blockIdx.z;
+    const int y = (int)blockIdx.y * CK_TR - CK + ry, xg = (int)blockIdx.x * CK_TG - 1 + gx;
+    const bool inimg = y >= 0 && y < H && xg >= 0 && xg < W4;
+    const bool intile = inimg && ry >= CK && ry < CK_ROWS - CK && gx >= 1 && gx < CK_GR - 1;
+    const int x = 4 * (inimg ? xg : 0);
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)b * HW + (size_t)(inimg ? y : 0) * W + x;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](const float* p) { return inimg ? *reinterpret_cast<const float4*>(p + idx) : z4; };
+    // the thread's own coefficients and constant term; the arithmetic below runs on pixel pairs (v_pk_fma_f32 / v_pk_mul_f32 /
+    // v_pk_add_f32: the pass is bound by VALU issue, not by memory)
+    v2f w[8][2], cp[2];
+    {
+        const float4 h0 = ld(blur);
+        v2f sw[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
-                    make_float4((1.f - m[0]) * dW[k][0], (1.f - m[1]) * dW[k][1], (1.f - m[2]) * dW[k][2], (1.f - m[3]) * dW[k][3]);
+        for (int k = 0; k < 8; ++k) {
+            const float4 q = ld(wf + (size_t)k * total);
+            w[k][0] = v2f{q.x, q.y}; w[k][1] = v2f{q.z, q.w};
+            sw[0] += w[k][0]; sw[1] += w[k][1];
         }
-        return;
-    }
-    // Two passes over the eight planes (the second re-reads its 4-column runs from cache) instead of keeping G, the raw values
-    // and dL/dw of all planes in registers: the kernel has to stay at 4+ waves per SIMD to hide its loads.
-    // G_k(p) = g~_k(p + off_k): a run of four columns of plane k in row y + dy_k starting at x + dx_k, zero outside the image
-    auto run = [&](int k, float (&v)[4]) -> bool {
-        const int yy = y + dy2(k), xs = x + dx2(k);
-        v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (yy < 0 || yy >= H) return false;
-        const float* src = gbp + k * HW + (size_t)yy * W;
-        if (xs >= 0 && xs + 3 < W) {
-            const float4 q = ld4u(src + xs);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sparse) { const float4 sq = ld(sparse); m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w); }
+        const float h0a[4] = {h0.x, h0.y, h0.z, h0.w};
+        float c[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (xs + i >= 0 && xs + i < W) v[i] = src[xs + i];
+        for (int i = 0; i < 4; ++i) c[i] = inimg ? (norm == CSPN_NORM_NONE ? m[i] * h0a[i] : h0a[i] * (1.f - (i < 2 ? sw[0][i] : sw[1][i - 2]))) : 0.f;
+        cp[0] = v2f{c[0], c[1]}; cp[1] = v2f{c[2], c[3]};
+    }
+    v2f dW[8][2], dC[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dW[k][0] = dW[k][1] = v2f{0.f, 0.f};
+    const v2f zero2 = {0.f, 0.f};
+    // the three rows around the thread's row of a level plane in LDS as pixel pairs: hp[d][o][half] = columns (x-1+o+2 half, +1) of
+    // row y+1 (d 0), y (1), y-1 (2), o = 0, 1, 2: what the taps dx = -1, 0, +1 multiply with
+    // (indices, not pointers: a pointer to a level plane that passes through a lambda or a select becomes a generic pointer and
+    // its reads flat loads that take the vector-memory path -- ten times an LDS read's latency; at the region's first / last
+    // row the thread reads its own row again: halo)
+    const int tdn_i = ry < CK_ROWS - 1 ? tid + CK_GR : tid, tup_i = ry > 0 ? tid - CK_GR : tid;
+    auto rows_of = [&](int l, v2f (&hp)[3][3][2]) {
+        const float4 own = sH[l][tid];
+        const float4 dn = sH[l][tdn_i], up = sH[l][tup_i];
+        const float4 q[3] = {dn, own, up};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float l = dpp_shr1(q[d].w), r = dpp_shl1(q[d].x);   // (the first / last lane of a region row gets 0: halo)
+            hp[d][0][0] = v2f{l, q[d].x};      hp[d][0][1] = v2f{q[d].y, q[d].z};
+            hp[d][1][0] = v2f{q[d].x, q[d].y}; hp[d][1][1] = v2f{q[d].z, q[d].w};
+            hp[d][2][0] = v2f{q[d].y, q[d].z}; hp[d][2][1] = v2f{q[d].w, r};
         }
-        return true;
     };
-    float om[4], ch[4], S[4] = {0.f, 0.f, 0.f, 0.f}, T1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float v[4];
-        run(k, v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
-            S[i] += fabsf(v[i]);
-            gs[i] += G;
-            T1[i] = fmaf(om[i] * (dW[k][i] - ch[i]), G, T1[i]);
+    // tap k multiplies with row d = (0,0,0,1,1,2,2,2)[k], column offset o = (2,1,0,2,0,2,1,0)[k]
+    auto seg_h = [&](int j) { return j == 0 ? ld(blur) : reg_to_img(ld(hh + (size_t)(j - 1) * total)); };            // H_{4j}
+    auto seg_a = [&](int j) { return j == NSEG - 1 ? ld(gout) : reg_to_img(ld(ah + (size_t)(NSEG - 2 - j) * total)); };   // A_{4j+4}
+    const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;   // a wave = 4 region rows: the first / last wave only feeds
+    constexpr bool PREFETCH = CK_ROWS != 32;
+    float4 nh = z4, na = z4;
+    if (PREFETCH) { nh = seg_h(0); na = seg_a(0); }
+    int par = 0;
+#ifdef BWD_EXP_NOLOOP
+    constexpr int NSEG_RUN = 0;
+#else
+    constexpr int NSEG_RUN = NSEG;
+#endif
+#pragma unroll 1
+    for (int j = 0; j < NSEG_RUN; ++j) {
+        float4 aq4;
+        if (PREFETCH) {
+            sH[0][tid] = nh;
+            aq4 = na;
+            if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
+        } else {
+            sH[0][tid] = seg_h(j);
+            aq4 = seg_a(j);   // (arrives under the three H steps)
         }
-    }
-    float rS[4], t2[4];
+        lds_barrier();
+#pragma unroll 1
+        for (int l = 0; l < CK - 1; ++l) {   // H_{s+l} -> H_{s+l+1}
+            v2f hp[3][3][2];
+            rows_of(l, hp);
+            v2f n[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { rS[i] = 1.f / S[i]; t2[i] = T1[i] / (S[i] * S[i]); }
-    if (gb) {
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] / S[i]) + m[i]);
-        *reinterpret_cast<float4*>(gb + idx) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    if (ggp) {
-        // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ys = y - dy2(k);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xq = x + i - dx2(k);
-                if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                v2f a = cp[hlf];
+                a = __builtin_elementwise_fma(w[0][hlf], hp[0][2][hlf], a); a = __builtin_elementwise_fma(w[1][hlf], hp[0][1][hlf], a);
+                a = __builtin_elementwise_fma(w[2][hlf], hp[0][0][hlf], a); a = __builtin_elementwise_fma(w[3][hlf], hp[1][2][hlf], a);
+                a = __builtin_elementwise_fma(w[4][hlf], hp[1][0][hlf], a); a = __builtin_elementwise_fma(w[5][hlf], hp[2][2][hlf], a);
+                a = __builtin_elementwise_fma(w[6][hlf], hp[2][1][hlf], a); a = __builtin_elementwise_fma(w[7][hlf], hp[2][0][hlf], a);
+                n[hlf] = inimg ? a : zero2;
             }
+            sH[l + 1][tid] = make_float4(n[0][0], n[0][1], n[1][0], n[1][1]);
+            lds_barrier();
         }
+        v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};   // A_{t+1}, t = s+3 first
+#pragma unroll 1
+        for (int l = CK - 1; l >= 0; --l) {
+            if (wave_in_tile_rows) {
+                v2f hp[3][3][2];
+                rows_of(l, hp);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v[4];
-            if (!run(k, v)) continue;  // the zero padding is a constant
-            const int yy = y + dy2(k), xs = x + dx2(k);
-            float d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
-                const float sg = G > 0.f ? 1.f : (G < 0.f ? -1.f : 0.f);
-                float r = om[i] * (dW[k][i] - ch[i]) * rS[i] - sg * t2[i];
-                if (norm == CSPN_NORM_8SUM_ABS) r *= v[i] > 0.f ? 1.f : (v[i] < 0.f ? -1.f : 0.f);
-                d[i] = r;
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    dC[hlf] += a[hlf];
+                    dW[0][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][2][hlf], dW[0][hlf]); dW[1][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][1][hlf], dW[1][hlf]);
+                    dW[2][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][0][hlf], dW[2][hlf]); dW[3][hlf] = __builtin_elementwise_fma(a[hlf], hp[1][2][hlf], dW[3][hlf]);
+                    dW[4][hlf] = __builtin_elementwise_fma(a[hlf], hp[1][0][hlf], dW[4][hlf]); dW[5][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][2][hlf], dW[5][hlf]);
+                    dW[6][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][1][hlf], dW[6][hlf]); dW[7][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][0][hlf], dW[7][hlf]);
+                }
             }
-            float* dst = ggp + k * HW + (size_t)yy * W;   // g_k(p + off_k) is read by pixel p only
-            if (xs >= 0 && xs + 3 < W) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
-            else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (xs + i >= 0 && xs + i < W) dst[xs + i] = d[i];
-            }
+            if (l == 0) break;
+            // A_t from A_{t+1}: P_k(p) = w'_k(p) A_{t+1}(p) goes to q = p + off_k; off_k = (+1,+1) (+1,0) (+1,-1) (0,+1) (0,-1) (-1,+1) (-1,0) (-1,-1).
+            // Column x' of the destination row takes P_k from column x' - dx_k of this row: dx = +1 -> the value one to the left.
+            v2f tdn[2], tup[2], mid[2];
+            auto send = [&](int k, v2f (&dst)[2], int dx, bool first) {
+                const v2f p0 = w[k][0] * a[0], p1 = w[k][1] * a[1];
+                v2f v0, v1;
+                if (dx > 0) { v0 = v2f{dpp_shr1(p1[1]), p0[0]}; v1 = v2f{p0[1], p1[0]}; }
+                else if (dx < 0) { v0 = v2f{p0[1], p1[0]}; v1 = v2f{p1[1], dpp_shl1(p0[0])}; }
+                else { v0 = p0; v1 = p1; }
+                dst[0] = first ? v0 : dst[0] + v0;
+                dst[1] = first ? v1 : dst[1] + v1;
+            };
+            send(0, tdn, 1, true); send(1, tdn, 0, false); send(2, tdn, -1, false);
+            send(3, mid, 1, true); send(4, mid, -1, false);
+            send(5, tup, 1, true); send(6, tup, 0, false); send(7, tup, -1, false);
+            sT[par][0][tid] = make_float4(tdn[0][0], tdn[0][1], tdn[1][0], tdn[1][1]);
+            sT[par][1][tid] = make_float4(tup[0][0], tup[0][1], tup[1][0], tup[1][1]);
+            lds_barrier();
+            const float4 fa = sT[par][0][tup_i];     // from the row above, sent down
+            const float4 fb = sT[par][1][tdn_i];     // from the row below, sent up
+            par ^= 1;
+            a[0] = inimg ? mid[0] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y} : zero2;
+            a[1] = inimg ? mid[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w} : zero2;
         }
+        lds_barrier();   // every read of this segment's level planes is done before the next segment overwrites them
     }
+#ifdef BWD_EXP_NOEPI
+    if (dC[0][0] != 12345.f) return;
+#endif
+    if (!intile) return;
+    float dWs[8][4], dCs[4] = {dC[0][0], dC[0][1], dC[1][0], dC[1][1]};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dWs[k][0] = dW[k][0][0]; dWs[k][1] = dW[k][0][1]; dWs[k][2] = dW[k][1][0]; dWs[k][3] = dW[k][1][1]; }
+    bwd_epilogue4(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
 }
 
 template <int RL>
@@ -464,9 +654,22 @@ static bool asm_path(int B, int H, int W, int n_iter) {
 
 size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     const size_t total = (size_t)B * H * W;
-    if (asm_path(B, H, W, n_iter))  // forward levels 23 + folded coefficients 8 + adjoint levels 23 + A_0 + a scratch output
-        return FRONT_PAD + (size_t)(23 + 8 + 23 + 2) * total * sizeof(float) + 256;
+    if (asm_path(B, H, W, n_iter))  // forward checkpoints 5 + folded coefficients 8 + adjoint checkpoints 5 + A_0 + a scratch output
+        return FRONT_PAD + (size_t)(NCKP + 8 + NCKP + 2) * total * sizeof(float) + 256;
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
+}
+
+// final pass of the assembly-sweep backward: from the checkpoints of both sweeps (CSPN_BWD_CK_ROWS=24|48: region rows, A/B)
+static void launch_final_ck(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* wf,
+                            const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
+    static const int rows = [] { const char* e = getenv("CSPN_BWD_CK_ROWS"); return e ? atoi(e) : 48; }();
+    const unsigned nbx = (unsigned)((W / 4 + CK_TG - 1) / CK_TG);
+    if (rows == 48)
+        hipLaunchKernelGGL(bwd_final_ck_kernel<48>, dim3(nbx, (H + 39) / 40, B), dim3(48 * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
+                           gg, gb, B, H, W, norm);
+    else
+        hipLaunchKernelGGL(bwd_final_ck_kernel<32>, dim3(nbx, (H + 23) / 24, B), dim3(32 * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
+                           gg, gb, B, H, W, norm);
 }
 
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
@@ -474,25 +677,19 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
     const size_t total = (size_t)B * H * W;
     float* wf = (float*)ws;
     if (asm_path(B, H, W, n_iter)) {
-        // both sweeps run in the fused ring kernel (cspn2d_tsw.hip), each writing its 23 intermediate levels: the forward
-        // as it is, the adjoint as a propagation whose coefficients are the folded planes read neighbour-sited with the
-        // channel order reversed (generator option adj)
-        // the forward sweep also leaves the 8 folded coefficient planes right behind its 23 level planes
+        // both sweeps run in the fused ring kernel (cspn2d_tsw.hip), each keeping every fourth of its levels: the forward
+        // as it is (it also leaves the 8 folded coefficient planes right behind its level planes), the adjoint as a
+        // propagation whose coefficients are those planes read neighbour-sited with the channel order reversed (generator
+        // option adj); the final pass recomputes the levels in between
         float* hh = (float*)((char*)ws + FRONT_PAD);
-        wf = hh + 23 * total;
+        wf = hh + NCKP * total;
         float* ah = wf + 8 * total;
-        float* a0 = ah + 23 * total;
+        float* a0 = ah + NCKP * total;
         float* scratch = a0 + total;
-        const unsigned blocks = (unsigned)((total + 255) / 256);
         if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, st, hh)) return e;
         if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-        static const bool final1 = getenv("CSPN_BWD_FINAL1") != nullptr;   // A/B switch: the one-pixel-per-thread final pass
-        if (final1)
-            hipLaunchKernelGGL(bwd_final_kernel<true>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B,
-                               H, W, n_iter, norm);
-        else
-            launch_final4(g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm, st);
-        return check_launch("bwd_final_kernel");
+        launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, st);
+        return check_launch("bwd_final_ck_kernel");
     }
     float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
     float* hh = wt + 8 * total;                       // H_1 .. H_{N-1}
@@ -513,10 +710,10 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
     return check_launch("bwd_final_kernel");
 }
 
-// ---- training mode: the forward keeps its level history, the backward starts from it ------------------------------------
-// history = [FRONT_PAD bytes][H_1 .. H_23][w'_0 .. w'_7] (what the forward sweep of backward2d leaves behind)
+// ---- training mode: the forward keeps its checkpoints, the backward starts from them ------------------------------------------
+// history = [FRONT_PAD bytes][H_4, H_8 .. H_20][w'_0 .. w'_7] (what the forward sweep of backward2d leaves behind)
 size_t history2d_bytes(int B, int H, int W, int n_iter) {
-    return asm_path(B, H, W, n_iter) ? FRONT_PAD + (size_t)(23 + 8) * B * H * W * sizeof(float) : 0;
+    return asm_path(B, H, W, n_iter) ? FRONT_PAD + (size_t)(NCKP + 8) * B * H * W * sizeof(float) : 0;
 }
 
 int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
@@ -527,19 +724,19 @@ int forward2d_history(const float* g, const float* blur, const float* sparse, fl
 }
 
 size_t backward2d_history_workspace(int B, int H, int W) {
-    return (size_t)(23 + 1) * B * H * W * sizeof(float) + 256;
+    return (size_t)(NCKP + 1) * B * H * W * sizeof(float) + 256;
 }
 
 int backward2d_history(const float* g, const float* blur, const float* sparse, const float* gout, const void* history, float* gg,
                        float* gb, int B, int H, int W, int norm, void* ws, hipStream_t st) {
     const size_t total = (size_t)B * H * W;
     const float* hh = (const float*)((const char*)history + FRONT_PAD);
-    const float* wf = hh + 23 * total;
+    const float* wf = hh + NCKP * total;
     float* ah = (float*)ws;
-    float* a0 = ah + 23 * total;
+    float* a0 = ah + NCKP * total;
     if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-    launch_final4(g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm, st);
-    return check_launch("bwd_final4_kernel");
+    launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, st);
+    return check_launch("bwd_final_ck_kernel");
 }
 
 }  // namespace cspn

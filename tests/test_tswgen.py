@@ -40,10 +40,12 @@ def test_emulated_sited8_input_variant(norm, sparse):
     assert nanmis == 0 and err <= 1e-4
 
 
-def test_emulated_history_variant_writes_every_level():
-    """cfg hist (used by the backward pass): levels 1..23 of every owned pixel, checked against the oracle level by level"""
+@pytest.mark.parametrize("every", [1, K.HIST_EVERY])
+def test_emulated_history_variant_writes_its_levels(every):
+    """cfg hist (used by the backward pass): the levels every, 2 every .. < 24 of every owned pixel (the product keeps every
+    fourth), checked against the oracle level by level"""
     os.chdir(ROOT)
-    err, nanmis, _, _ = run_case(2, 11, 304, 4, 0, True, False, seed=3, verbose=False, hist=True)
+    err, nanmis, _, _ = run_case(2, 11, 304, 4, 0, True, False, seed=3, verbose=False, hist=True, hist_every=every)
     assert nanmis == 0 and err <= 1e-4
 
 
@@ -65,7 +67,9 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
             nxt += _shift(wp[k] * cur, -DY[k], -DX[k])
         cur = nxt.astype(np.float32)
         levels.append(cur)
-    prog = K.build(dict(norm=2, adj=True, hist=True))
+    every = K.HIST_EVERY
+    npl = 24 // every - 1
+    prog = K.build(dict(norm=2, adj=True, hist=True, hist_every=every))
     assert not check_hazards(prog)
     n_wg = -(-n_wg // len(plan_bands(W, 24))) * len(plan_bands(W, 24))
     hdr, tab = build_plan(B, H, W, 24, n_wg)
@@ -92,10 +96,12 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
             w.s[K.S_NROWS.i], w.s[K.S_LOHI.i] = tab.shape[1], int(hdr[wg, 2])
         emu.run()
     out = mem[off["out"]:off["out"] + total * 4].view(np.float32).reshape(B, H, W)
-    hb = mem[off["hist"]:off["hist"] + 23 * total * 4].view(np.float32).reshape(23, B, H, W // 4, 4)[..., [0, 2, 3, 1]].reshape(23, B, H, W)
+    hb = mem[off["hist"]:off["hist"] + npl * total * 4].view(np.float32).reshape(npl, B, H, W // 4, 4)[..., [0, 2, 3, 1]].reshape(npl, B, H, W)
     assert np.abs(out - levels[23]).max() <= 1e-5 * np.abs(levels[23]).max()
-    for n in range(1, 24):
-        assert np.abs(hb[n - 1] - levels[n - 1]).max() <= 1e-5 * np.abs(levels[n - 1]).max(), n
+    for i in range(npl):   # plane i = level (i + 1) * every of the sweep = A_{24 - (i + 1) every}
+        n = (i + 1) * every
+        assert np.abs(hb[i] - levels[n - 1]).max() <= 1e-5 * np.abs(levels[n - 1]).max(), n
+    assert np.isnan(mem[off["hist"] + npl * total * 4:off["hist"] + 23 * total * 4].view(np.float32)).all()   # nothing behind them
 
 
 def test_generated_include_is_current_and_hazard_free():
@@ -104,10 +110,10 @@ def test_generated_include_is_current_and_hazard_free():
         p = K.build(dict(norm=norm, sparse=bool(sparse), hin=bool(hin)))
         assert not check_hazards(p)
         assert ("#define TSW_ASM_%d_%d_%d R\"ASM(\n%s\n)ASM\"" % (norm, sparse, hin, p.text())) in inc
-    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True))
+    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True, hist_every=K.HIST_EVERY))
     assert not check_hazards(p)
     assert ("#define TSW_ASM_HIST_2_0 R\"ASM(\n%s\n)ASM\"" % p.text()) in inc
-    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True, adj=True))
+    p = K.build(dict(norm=2, sparse=False, hin=False, hist=True, adj=True, hist_every=K.HIST_EVERY))
     assert ("#define TSW_ASM_ADJ R\"ASM(\n%s\n)ASM\"" % p.text()) in inc
 
 

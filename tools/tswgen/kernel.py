@@ -15,6 +15,7 @@ n_iter (only 24 for now).
 from .isa import Prog, V, S, EXEC, VCC, schedule, check_hazards, expand_pseudos
 
 NW, NSLOT, LV = 8, 4, 24
+HIST_EVERY = 4   # the history / adjoint variants of the product keep every fourth level (cfg hist_every; cspn2d_backward.hip recomputes the rest)
 PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgroup's stream
 DESC_BYTES = 16              # goff_lo, goff_hi, boff, flags | lo << 8 | hi << 20
 # ring of cooked rows: 8 slots x 64 lane records; a record = [plane 0..9][column 0..3] floats + 2 pad = 42 dwords, so that the
@@ -118,6 +119,10 @@ class Gen(object):
         self.p = Prog()
         self.norm, self.sparse, self.hin = cfg.get("norm", 0), cfg.get("sparse", False), cfg.get("hin", False)
         self.hist = cfg.get("hist", False)
+        # history mode keeps the levels that are multiples of hist_every (1: all of 1..23; 4: the checkpoints 4, 8 .. 20 the
+        # recomputing final pass of the backward starts from); plane i of the history = level (i + 1) * hist_every
+        self.hist_every = cfg.get("hist_every", 1)
+        assert 24 % self.hist_every == 0
         # adj: the adjoint sweep of the backward pass as a propagation.  Coefficients come from the folded planes w'
         # ([8][B*H*W], what fold2d_kernel writes) read neighbour-sited with the channel order reversed --
         # G_k(p) = w'_{7-k}(p + off_k), since off_{7-k} = -off_k -- and are used as they are (no normalisation, c' = 0)
@@ -496,7 +501,7 @@ class Gen(object):
                     vq = hn
             elif "noact" not in self.ab and (slow or not act_fast):
                 self.act_check(j, vq)
-            if self.hist and ev != j:
+            if self.hist and ev != j and ((c - j) % LV) % self.hist_every == 0:   # slot j has just completed level (c - j) mod 24
                 self.hist_store(j, vq)
             if j == 3 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024, at=0.0)
@@ -885,9 +890,10 @@ class Gen(object):
                 e("s_mov_b64", S_HM[j], [0])
                 e("s_mov_b64", S_HB[j], [S_HIST])
             # cooking lanes inside the owned columns: 4*xb (V_OFF1, set below) against 4*lo, 4*hi -- computed after V_OFF1
-            e("s_mul_i32", T[2], [S_HSTRIDE[0], 23])
-            e("s_mul_hi_u32", T[3], [S_HSTRIDE[0], 23])
-            e("s_mul_i32", T[4], [S_HSTRIDE[1], 23])
+            npl = LV // self.hist_every - 1   # level planes in front of the coefficient planes
+            e("s_mul_i32", T[2], [S_HSTRIDE[0], npl])
+            e("s_mul_hi_u32", T[3], [S_HSTRIDE[0], npl])
+            e("s_mul_i32", T[4], [S_HSTRIDE[1], npl])
             e("s_add_i32", T[3], [T[3], T[4]])
             e("s_add_u32", S_WF[0], [S_HIST[0], T[2]])
             e("s_addc_u32", S_WF[1], [S_HIST[1], T[3]])

@@ -10,7 +10,7 @@ from .emu import Emu, EmuError
 from .plan import build_plan
 
 
-def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False,
+def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False, hist_every=1,
              s8=False, elastic=False, sched_seed=None):
     sys.path.insert(0, ".")
     from oracle import oracle as O
@@ -31,7 +31,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
     K.configure(elastic)
-    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {})), sched=sched)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, hist_every=hist_every, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {})), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
@@ -98,19 +98,21 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none"][norm])
     if hist:
         assert not hin
-        wfb = mem[off["hist"] + 23 * blur.nbytes:off["hist"] + 31 * blur.nbytes].view(np.float32).reshape(8, B, H, W)
+        npl = 24 // hist_every - 1   # level planes: levels hist_every, 2 hist_every ..
+        wfb = mem[off["hist"] + npl * blur.nbytes:off["hist"] + (npl + 8) * blur.nbytes].view(np.float32).reshape(8, B, H, W)
         wf_ref = folded_planes(g, sp, norm)
         assert np.array_equal(np.isnan(wfb), np.isnan(wf_ref))
         assert np.nanmax(np.abs(wfb - wf_ref)) <= 1e-6 * max(1.0, np.nanmax(np.abs(wf_ref))), "folded coefficient planes"
-        hb = mem[off["hist"]:off["hist"] + 23 * blur.nbytes].view(np.float32).reshape(23, B, H, W // 4, 4)
-        hb = hb[..., [0, 2, 3, 1]].reshape(23, B, 1, H, W)   # stored in register order (c0,c3,c1,c2) per 4-column group
+        hb = mem[off["hist"]:off["hist"] + npl * blur.nbytes].view(np.float32).reshape(npl, B, H, W // 4, 4)
+        hb = hb[..., [0, 2, 3, 1]].reshape(npl, B, 1, H, W)   # stored in register order (c0,c3,c1,c2) per 4-column group
         worst = 0.0
-        for lv in range(1, 24):
+        for i in range(npl):
+            lv = (i + 1) * hist_every
             r = O.cspn2d_oracle(g, blur, sp, lv, ["8sum", "8sum_abs", "none"][norm])
-            assert np.array_equal(np.isnan(hb[lv - 1]), np.isnan(r)), "history level %d: NaN pattern" % lv
-            worst = max(worst, float(np.nanmax(np.abs(hb[lv - 1] - r)) / np.nanmax(np.abs(r))))
+            assert np.array_equal(np.isnan(hb[i]), np.isnan(r)), "history level %d: NaN pattern" % lv
+            worst = max(worst, float(np.nanmax(np.abs(hb[i] - r)) / np.nanmax(np.abs(r))))
         if verbose:
-            print("   history levels 1..23: worst rel err %.3g" % worst)
+            print("   history levels %s: worst rel err %.3g" % (list(range(hist_every, 24, hist_every)), worst))
         assert worst <= 1e-5
     nanmis = np.isnan(out) != np.isnan(ref)
     den = np.nanmax(np.abs(ref))
