@@ -250,22 +250,25 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     }
     float rS[4], t2[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { rS[i] = 1.f / S[i]; t2[i] = T1[i] / (S[i] * S[i]); }
+    for (int i = 0; i < 4; ++i) { rS[i] = __builtin_amdgcn_rcpf(S[i]); t2[i] = T1[i] * rS[i] * rS[i]; }   // (v_rcp_f32: 1 ulp; three IEEE divisions per pixel were ~150 instructions per thread)
     if (gb) {
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] / S[i]) + m[i]);
+        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] * rS[i]) + m[i]);
         *reinterpret_cast<float4*>(gb + idx) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (ggp) {
         // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
+        // (only groups on the image's border have such elements)
+        if (y == 0 || y == H - 1 || x == 0 || x + 4 >= W) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ys = y - dy2(k);
+            for (int k = 0; k < 8; ++k) {
+                const int ys = y - dy2(k);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xq = x + i - dx2(k);
-                if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    const int xq = x + i - dx2(k);
+                    if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+                }
             }
         }
 #pragma unroll
@@ -473,7 +476,8 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
     float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
     constexpr int N = 24, NSEG = N / CK, CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
-    __shared__ __attribute__((aligned(16))) float4 sH[CK][CK_NT];      // H_s .. H_{s+3} of the region (image order inside a quad)
+    __shared__ __attribute__((aligned(16))) float4 sH[2][CK_NT];       // H_{s+l} of the region, two planes alternating (image order inside a quad)
+    __shared__ __attribute__((aligned(16))) float4 sA[CK][CK_NT];      // A_{s+1} .. A_{s+4}: every thread's own group only
     __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
     const int tid = threadIdx.x, gx = tid & (CK_GR - 1), ry = tid >> 4;
     const int W4 = W >> 2, b = blockIdx.z;
@@ -515,9 +519,10 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     // its reads flat loads that take the vector-memory path -- ten times an LDS read's latency; at the region's first / last
     // row the thread reads its own row again: halo)
     const int tdn_i = ry < CK_ROWS - 1 ? tid + CK_GR : tid, tup_i = ry > 0 ? tid - CK_GR : tid;
-    auto rows_of = [&](int l, v2f (&hp)[3][3][2]) {
-        const float4 own = sH[l][tid];
-        const float4 dn = sH[l][tdn_i], up = sH[l][tup_i];
+    // pixel pairs of the three rows around the thread's row: hp[d][o][half] = columns (x-1+o+2 half, +1) of row y+1 (d 0), y (1),
+    // y-1 (2), o = 0, 1, 2: what the taps dx = -1, 0, +1 multiply with.  The own row comes from the registers.
+    auto rows_of = [&](int pl, const float4 own, v2f (&hp)[3][3][2]) {
+        const float4 dn = sH[pl][tdn_i], up = sH[pl][tup_i];
         const float4 q[3] = {dn, own, up};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -542,49 +547,21 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
 #endif
 #pragma unroll 1
     for (int j = 0; j < NSEG_RUN; ++j) {
-        float4 aq4;
+        float4 hq, aq4;   // H_s, A_{s+4} of the thread's group
         if (PREFETCH) {
-            sH[0][tid] = nh;
+            hq = nh;
             aq4 = na;
             if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
         } else {
-            sH[0][tid] = seg_h(j);
-            aq4 = seg_a(j);   // (arrives under the three H steps)
+            aq4 = seg_a(j);
+            hq = seg_h(j);   // (arrives under the three adjoint steps)
         }
-        lds_barrier();
+        // ---- the adjoint levels first (they do not depend on H): A_{s+4} -> A_{s+3}, A_{s+2}, A_{s+1}, each parked in the thread's
+        // own LDS slot (sA[i] = A_{s+i+1}; nobody else reads it: no barrier for these)
+        v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};
+        sA[CK - 1][tid] = aq4;
 #pragma unroll 1
-        for (int l = 0; l < CK - 1; ++l) {   // H_{s+l} -> H_{s+l+1}
-            v2f hp[3][3][2];
-            rows_of(l, hp);
-            v2f n[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                v2f a = cp[hlf];
-                a = __builtin_elementwise_fma(w[0][hlf], hp[0][2][hlf], a); a = __builtin_elementwise_fma(w[1][hlf], hp[0][1][hlf], a);
-                a = __builtin_elementwise_fma(w[2][hlf], hp[0][0][hlf], a); a = __builtin_elementwise_fma(w[3][hlf], hp[1][2][hlf], a);
-                a = __builtin_elementwise_fma(w[4][hlf], hp[1][0][hlf], a); a = __builtin_elementwise_fma(w[5][hlf], hp[2][2][hlf], a);
-                a = __builtin_elementwise_fma(w[6][hlf], hp[2][1][hlf], a); a = __builtin_elementwise_fma(w[7][hlf], hp[2][0][hlf], a);
-                n[hlf] = inimg ? a : zero2;
-            }
-            sH[l + 1][tid] = make_float4(n[0][0], n[0][1], n[1][0], n[1][1]);
-            lds_barrier();
-        }
-        v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};   // A_{t+1}, t = s+3 first
-#pragma unroll 1
-        for (int l = CK - 1; l >= 0; --l) {
-            if (wave_in_tile_rows) {
-                v2f hp[3][3][2];
-                rows_of(l, hp);
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    dC[hlf] += a[hlf];
-                    dW[0][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][2][hlf], dW[0][hlf]); dW[1][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][1][hlf], dW[1][hlf]);
-                    dW[2][hlf] = __builtin_elementwise_fma(a[hlf], hp[0][0][hlf], dW[2][hlf]); dW[3][hlf] = __builtin_elementwise_fma(a[hlf], hp[1][2][hlf], dW[3][hlf]);
-                    dW[4][hlf] = __builtin_elementwise_fma(a[hlf], hp[1][0][hlf], dW[4][hlf]); dW[5][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][2][hlf], dW[5][hlf]);
-                    dW[6][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][1][hlf], dW[6][hlf]); dW[7][hlf] = __builtin_elementwise_fma(a[hlf], hp[2][0][hlf], dW[7][hlf]);
-                }
-            }
-            if (l == 0) break;
+        for (int l = CK - 1; l >= 1; --l) {
             // A_t from A_{t+1}: P_k(p) = w'_k(p) A_{t+1}(p) goes to q = p + off_k; off_k = (+1,+1) (+1,0) (+1,-1) (0,+1) (0,-1) (-1,+1) (-1,0) (-1,-1).
             // Column x' of the destination row takes P_k from column x' - dx_k of this row: dx = +1 -> the value one to the left.
             v2f tdn[2], tup[2], mid[2];
@@ -608,8 +585,42 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
             par ^= 1;
             a[0] = inimg ? mid[0] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y} : zero2;
             a[1] = inimg ? mid[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w} : zero2;
+            sA[l - 1][tid] = make_float4(a[0][0], a[0][1], a[1][0], a[1][1]);
         }
-        lds_barrier();   // every read of this segment's level planes is done before the next segment overwrites them
+        // ---- then H_s -> H_{s+3}; the pixel pairs built for a step are also what A_{t+1} multiplies with for dW'
+        sH[0][tid] = hq;
+        lds_barrier();
+#pragma unroll 1
+        for (int l = 0; l < CK; ++l) {
+            v2f hp[3][3][2];
+            rows_of(l & 1, hq, hp);
+            if (wave_in_tile_rows) {
+                const float4 aq = sA[l][tid];   // A_{s+l+1}
+                const v2f av[2] = {v2f{aq.x, aq.y}, v2f{aq.z, aq.w}};
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    dC[hlf] += av[hlf];
+                    dW[0][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][2][hlf], dW[0][hlf]); dW[1][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][1][hlf], dW[1][hlf]);
+                    dW[2][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][0][hlf], dW[2][hlf]); dW[3][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][2][hlf], dW[3][hlf]);
+                    dW[4][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][0][hlf], dW[4][hlf]); dW[5][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][2][hlf], dW[5][hlf]);
+                    dW[6][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][1][hlf], dW[6][hlf]); dW[7][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][0][hlf], dW[7][hlf]);
+                }
+            }
+            if (l == CK - 1) break;
+            v2f n[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                v2f t = cp[hlf];
+                t = __builtin_elementwise_fma(w[0][hlf], hp[0][2][hlf], t); t = __builtin_elementwise_fma(w[1][hlf], hp[0][1][hlf], t);
+                t = __builtin_elementwise_fma(w[2][hlf], hp[0][0][hlf], t); t = __builtin_elementwise_fma(w[3][hlf], hp[1][2][hlf], t);
+                t = __builtin_elementwise_fma(w[4][hlf], hp[1][0][hlf], t); t = __builtin_elementwise_fma(w[5][hlf], hp[2][2][hlf], t);
+                t = __builtin_elementwise_fma(w[6][hlf], hp[2][1][hlf], t); t = __builtin_elementwise_fma(w[7][hlf], hp[2][0][hlf], t);
+                n[hlf] = inimg ? t : zero2;
+            }
+            hq = make_float4(n[0][0], n[0][1], n[1][0], n[1][1]);
+            sH[(l + 1) & 1][tid] = hq;   // (the plane read two steps ago: everybody is past the barrier in between)
+            lds_barrier();
+        }
     }
 #ifdef BWD_EXP_NOEPI
     if (dC[0][0] != 12345.f) return;
