@@ -1,6 +1,6 @@
 // cspn2d_backward.hip -- gradient of Affinity_Propagate.forward (reference cspn_pytorch/models/cspn.py:42-83) with respect
 // to guidance and blur_depth: what torch autograd computes when reference train.py:196-198 back-propagates through the
-// module.  First version: correct and coalesced, one launch per iteration; not yet fused.
+// module.
 //
 // Forward, folded (cspn2d_stepwise.hip):  H_{t+1} = c' + sum_k w'_k * shift_k(H_t),  w'_k = (1-m) w_k,
 //   c' = (1-m)(1-sigma) H_0 + m H_0,  w_k = G_k / S,  S = sum_j |G_j|,  G_k(p) = g~_k(p + off_k),  sigma = sum_k w_k.
@@ -9,8 +9,11 @@
 //           dL/dw_k = (1-m)(dW'_k - dC H_0);   dL/dH_0 = A_0 + dC ((1-m)(1-sigma) + m)
 //           dL/dG_k = dL/dw_k / S - sign(G_k) (sum_j dL/dw_j G_j) / S^2          (torch: d|x|/dx = sign(x), 0 at 0)
 //           dL/dg_k(p + off_k) = dL/dG_k(p)  [* sign(g) for '8sum_abs'];  elements no pixel reads get 0.
-// The H_t history is recomputed here with the stepwise kernels (the fused forward keeps nothing).
+// 24-iteration passes on images the ring kernel takes: two sweeps of that kernel (forward keeping H_4, H_8 .. H_20 and the folded
+// coefficients, adjoint keeping A_20 .. A_4) + bwd_final_ck_kernel, which recomputes the levels in between tile by tile.
+// Everything else: fold + one launch per step for both recursions (every level kept) + bwd_final_kernel.
 #include <cstdlib>
+#include <type_traits>
 
 #include "cspn_common.h"
 
@@ -64,17 +67,10 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const float* __restrict__
     aout[idx] = acc;
 }
 
-__device__ __forceinline__ size_t swz(size_t i) {  // register order (c0,c3,c1,c2) inside each aligned group of 4 columns
-    const size_t e = i & 3;                           // (tools/tswgen/kernel.py: the pairs X = (c0,c3), Y = (c1,c2))
-    return (i & ~(size_t)3) | (e == 1 ? 2 : (e == 2 ? 3 : (e == 3 ? 1 : 0)));
-}
-
-// hh: H_1 .. H_{N-1} (H_0 = blur).  SWZ = false: ah = A_0 .. A_{N-1}, plain layout (stepwise sweeps).
-// SWZ = true (assembly passes, N = 24): hh and ah are level histories in register order; ah level n = A_{24-n}, a0p = A_0.
-template <bool SWZ>
+// final pass of the stepwise sweeps (every level kept): hh = H_1 .. H_{N-1} (H_0 = blur), ah = A_0 .. A_{N-1}
 __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict__ g, const float* __restrict__ blur,
                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
-                                                         const float* __restrict__ ah, const float* __restrict__ a0p,
+                                                         const float* __restrict__ ah,
                                                          const float* __restrict__ gout,
                                                          float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W,
                                                          int n_iter, int norm) {
@@ -97,20 +93,20 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
     for (int t = 0; t < n_iter; ++t) {
         float a;
         if (t + 1 == n_iter) a = gout[idx];
-        else a = SWZ ? ah[(size_t)(n_iter - 2 - t) * total + swz(idx)] : ah[(size_t)(t + 1) * total + idx];
+        else a = ah[(size_t)(t + 1) * total + idx];
         const float* ht = (t == 0) ? blur : hh + (size_t)(t - 1) * total;
         dC += a;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float hv = 0.f;
-            if (ok[k]) hv = (SWZ && t > 0) ? ht[swz(base + noff[k])] : ht[base + noff[k]];
+            if (ok[k]) hv = ht[base + noff[k]];
             dW[k] = fmaf(a, hv, dW[k]);
         }
     }
     const float h0 = blur[idx];
     const float m = sparse ? signf(sparse[idx]) : 0.f;
     const float om = 1.f - m;
-    const float a0 = SWZ ? a0p[idx] : ah[idx];
+    const float a0 = ah[idx];
     const float* gbp = g + (size_t)b * 8 * HW;
     if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
         if (gb) gb[idx] = a0 + dC * m;
@@ -159,11 +155,7 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
 }
 
 
-// ---- final pass for the assembly sweeps, 4 columns (one register-order group) per thread -------------------------------
-// Same arithmetic as bwd_final_kernel<true>.  Per level a thread reads its group of A (16 bytes) and, for each of the three
-// neighbour rows, its group of H (16 bytes) plus the two single columns beside it: 10 loads for 4 pixels instead of 36, and
-// the 32 dW' products of a level come out of registers.  The epilogue reads / writes the eight guidance planes as 4-column
-// runs (16-byte accesses at 4-byte alignment where the run lies inside the row).
+// ---- helpers of the final pass of the assembly sweeps: one group of 4 columns per thread ------------------------------
 __device__ __forceinline__ float dpp_shr1(float v) {   // within each row of 16 lanes: lane i <- lane i-1 (first lane: 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
 }
@@ -177,16 +169,7 @@ __device__ __forceinline__ float4 ld4u(const float* p) {   // 16 bytes, 4-byte a
 }
 __device__ __forceinline__ void st4u(float* p, float4 v) { __builtin_memcpy(p, &v, 16); }
 
-__device__ __forceinline__ float dpp_wshr1(float v) {   // across the wave: lane i <- lane i-1 (lane 0: 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   // wave_shr:1
-}
-__device__ __forceinline__ float dpp_wshl1(float v) {   // across the wave: lane i <- lane i+1 (lane 63: 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));   // wave_shl:1
-}
-
-// RL = lanes per image row inside a wave: 16 (a wave = 4 rows x 16 groups, a block = 16 rows x 64 columns) or 64 (a wave = one
-// row of 64 groups = 1 KB per load, a block = 4 rows x 256 columns, blocks numbered so that vertical neighbours share an XCD)
-// ---- the end of the final pass for one register-order group of 4 columns (b, y, x .. x + 3): from dW'_k and dC through the fold,
+// ---- the end of the final pass for one group of 4 columns (b, y, x .. x + 3): from dW'_k and dC through the fold,
 // the normalisation and the neighbour-sited gather to dL/dguidance and dL/dblur_depth (see the file header)
 __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse,
                                               const float* __restrict__ a0p, float* __restrict__ gg, float* __restrict__ gb, int b, int y,
@@ -296,153 +279,6 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     }
 }
 
-// NB = level buffers: NB - 1 levels are in flight while one is being multiplied.  2 at three waves per SIMD is what ships: 3 buffers
-// need 224 registers (two waves per SIMD) and ran 1.53 ms against 1.41 (profiles/r03_backward_final_variants.txt)
-template <int RL, int NB>
-__device__ __forceinline__ void bwd_final4_body(const float* __restrict__ g, const float* __restrict__ blur,
-                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
-                                                          const float* __restrict__ ah, const float* __restrict__ a0p,
-                                                          const float* __restrict__ gout, float* __restrict__ gg,
-                                                          float* __restrict__ gb, int B, int H, int W, int norm) {
-    constexpr int N = 24;
-    const int W4 = W >> 2;
-    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
-    // a block = 16 rows x 16 groups (64 columns): a wave holds 4 rows of 16 groups, so the rows above / below a thread's row are
-    // read by the same CU (L1) instead of by another XCD, and the columns beside a group come from the neighbouring lane of
-    // the 16-lane DPP row
-    const int lane = threadIdx.x & 63, gx = lane & (RL - 1);
-    int b, y, xg;
-    if (RL == 16) {
-        b = blockIdx.z;
-        y = blockIdx.y * 16 + ((threadIdx.x >> 6) << 2) + (lane >> 4);
-        xg = blockIdx.x * 16 + gx;
-    } else {
-        // 1-D grid; hardware deals block i to XCD i % 8: give every XCD a contiguous run of tiles, numbered rows-first inside a
-        // (image, column-of-blocks) strip, so that the blocks above / below a block run on the same XCD at about the same time
-        const int nbx = (W4 + 63) / 64, nby = (H + 3) / 4, ntile = nbx * nby * B, per = (ntile + 7) / 8;
-        const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-        const bool live = t < ntile && (int)(blockIdx.x >> 3) < per;
-        const int tt = live ? t : 0;
-        const int by = tt % nby, r = tt / nby, bx = r % nbx;
-        b = r / nbx;
-        y = live ? by * 4 + (int)(threadIdx.x >> 6) : H;
-        xg = bx * 64 + gx;
-    }
-    const bool valid = y < H && xg < W4;
-    const int x = 4 * (valid ? xg : 0);
-    const size_t base = (size_t)b * HW, idx = base + (size_t)(valid ? y : 0) * W + x;
-    float dW[8][4], dC[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dW[k][i] = 0.f;
-    // One level = A_{t+1} times the three rows of H_t around the thread's row.  All ten loads of a level (A, three H groups, the
-    // columns beside the group for the end lanes of a 16-lane row) are issued together and one level AHEAD of the arithmetic, so
-    // that a wave always has a level in flight (issued one by one behind their uses, every load paid a full memory round trip).
-    // RL == 16: a wave holds four consecutive image rows (16 lanes each), so the H row above / below a lane's row IS the own row of
-    // the lane 16 further down / up: only the wave's first / last row of lanes load theirs, the others take it from that lane with
-    // ds_bpermute_b32 once the level has arrived -- 1 + 1 + 2 x 1/4 quad loads per lane and level instead of 4 (the pass was
-    // running the L1 request path at ~3/4 of its rate: 4 KB of requests per wave and level at 64 B/clk, twelve waves per CU).
-    constexpr bool VSHARE = RL == 16;
-    const int lrow = lane >> 4;   // (RL == 16) the lane's row inside the wave
-    struct Lvl { float4 a, r[3]; float e0[3], e5[3]; };
-    // t = 0: H_0 = blur (image order), A_1 = adjoint level N-2;  t = 1..N-2: histories;  t = N-1: A_N = dL/dout (image order)
-    auto fetch = [&](int t, Lvl& L, bool first, bool last) {
-        const float* ap = last ? gout : ah + (size_t)(N - 2 - t) * total;
-        const float* ht = first ? blur : hh + (size_t)(t - 1) * total;
-        const bool h_reg_order = !first;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.a = z4;
-        if (valid) L.a = *reinterpret_cast<const float4*>(ap + idx);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1
-            const int yy = y + 1 - d;
-            bool rowin = valid && yy >= 0 && yy < H;
-            if (VSHARE && ((d == 0 && lrow < 3) || (d == 2 && lrow > 0))) rowin = false;   // comes from the lane 16 down / up
-            const float* row = ht + base + (size_t)(rowin ? yy : 0) * W;
-            L.r[d] = z4;
-            L.e0[d] = L.e5[d] = 0.f;
-            if (rowin) L.r[d] = *reinterpret_cast<const float4*>(row + x);
-            // c3 of the group to the left sits at position 1 of a register-order group, c0 of the group to the right at position 0
-            if (gx == 0 && rowin && x > 0) L.e0[d] = row[h_reg_order ? x - 4 + 1 : x - 1];
-            if (gx == RL - 1 && rowin && x + 4 < W) L.e5[d] = row[x + 4];
-        }
-    };
-    auto from_lane = [&](float v, int src_lane) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
-    };
-    auto compute = [&](Lvl& L, bool first, bool last) {
-        if (VSHARE) {   // rows above / below from the neighbouring rows of lanes (an invalid lane holds zeros: outside the image)
-            const int dn = (lane + 16) & 63, up = (lane - 16) & 63;
-            const float4 o = L.r[1];
-            const float4 fd = make_float4(from_lane(o.x, dn), from_lane(o.y, dn), from_lane(o.z, dn), from_lane(o.w, dn));
-            const float4 fu = make_float4(from_lane(o.x, up), from_lane(o.y, up), from_lane(o.z, up), from_lane(o.w, up));
-            const float e0d = from_lane(L.e0[1], dn), e5d = from_lane(L.e5[1], dn);
-            const float e0u = from_lane(L.e0[1], up), e5u = from_lane(L.e5[1], up);
-            if (lrow < 3) { L.r[0] = fd; L.e0[0] = e0d; L.e5[0] = e5d; }
-            if (lrow > 0) { L.r[2] = fu; L.e0[2] = e0u; L.e5[2] = e5u; }
-        }
-        const bool a_reg_order = !last, h_reg_order = !first;
-        float a[4];
-        if (a_reg_order) { a[0] = L.a.x; a[1] = L.a.z; a[2] = L.a.w; a[3] = L.a.y; }   // (c0,c3,c1,c2)
-        else { a[0] = L.a.x; a[1] = L.a.y; a[2] = L.a.z; a[3] = L.a.w; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dC[i] += a[i];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {   // dy = 1, 0, -1: planes 0..2, 3..4, 5..7
-            float h[6];   // columns x-1 .. x+4
-            const float4 q = L.r[d];
-            if (!h_reg_order) { h[1] = q.x; h[2] = q.y; h[3] = q.z; h[4] = q.w; }
-            else { h[1] = q.x; h[2] = q.z; h[3] = q.w; h[4] = q.y; }
-            // the columns beside the group belong to the neighbouring lanes (the next / previous group of the same row); the end
-            // lanes of a 16-lane row have fetched theirs (0 outside the image)
-            h[0] = RL == 16 ? dpp_shr1(h[4]) : dpp_wshr1(h[4]);
-            h[5] = RL == 16 ? dpp_shl1(h[1]) : dpp_wshl1(h[1]);
-            if (gx == 0) h[0] = L.e0[d];
-            if (gx == RL - 1) h[5] = L.e5[d];
-            if (x + 4 >= W) h[5] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (d == 0) {
-                    dW[0][i] = fmaf(a[i], h[i + 2], dW[0][i]);
-                    dW[1][i] = fmaf(a[i], h[i + 1], dW[1][i]);
-                    dW[2][i] = fmaf(a[i], h[i], dW[2][i]);
-                } else if (d == 1) {
-                    dW[3][i] = fmaf(a[i], h[i + 2], dW[3][i]);
-                    dW[4][i] = fmaf(a[i], h[i], dW[4][i]);
-                } else {
-                    dW[5][i] = fmaf(a[i], h[i + 2], dW[5][i]);
-                    dW[6][i] = fmaf(a[i], h[i + 1], dW[6][i]);
-                    dW[7][i] = fmaf(a[i], h[i], dW[7][i]);
-                }
-            }
-        }
-    };
-    static_assert(N % NB == 0 && N / NB >= 2, "the level loop rotates NB buffers");
-    {
-        Lvl L[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) fetch(i, L[i], i == 0, false);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {   // levels 0 .. NB - 1
-            compute(L[i], i == 0, false);
-            fetch(NB + i, L[i], false, NB + i == N - 1);
-        }
-#pragma unroll 1
-        for (int t = NB; t < N - NB; t += NB) {   // L[i] holds level t + i
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                compute(L[i], false, false);
-                fetch(t + NB + i, L[i], false, t + NB + i == N - 1);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) compute(L[i], false, i == NB - 1);   // levels N - NB .. N - 1
-    }
-    if (!valid) return;
-    bwd_epilogue4(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dW, dC);
-}
-
 // ---- final pass from CHECKPOINTS (round 3): the sweeps keep every fourth level only ----------------------------------------
 // The forward sweep stores H_4, H_8 .. H_20, the adjoint sweep A_20, A_16 .. A_4 (generator option hist_every; H_0 = blur and
 // A_24 = dL/dout are inputs): 10 level planes through HBM instead of 46.  This pass recomputes the three levels in between,
@@ -536,7 +372,7 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     auto seg_h = [&](int j) { return j == 0 ? ld(blur) : reg_to_img(ld(hh + (size_t)(j - 1) * total)); };            // H_{4j}
     auto seg_a = [&](int j) { return j == NSEG - 1 ? ld(gout) : reg_to_img(ld(ah + (size_t)(NSEG - 2 - j) * total)); };   // A_{4j+4}
     const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;   // a wave = 4 region rows: the first / last wave only feeds
-    constexpr bool PREFETCH = CK_ROWS != 32;
+    constexpr bool PREFETCH = CK_ROWS == 48;
     float4 nh = z4, na = z4;
     if (PREFETCH) { nh = seg_h(0); na = seg_a(0); }
     int par = 0;
@@ -545,83 +381,93 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
 #else
     constexpr int NSEG_RUN = NSEG;
 #endif
-#pragma unroll 1
-    for (int j = 0; j < NSEG_RUN; ++j) {
-        float4 hq, aq4;   // H_s, A_{s+4} of the thread's group
-        if (PREFETCH) {
-            hq = nh;
-            aq4 = na;
-            if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
-        } else {
-            aq4 = seg_a(j);
-            hq = seg_h(j);   // (arrives under the three adjoint steps)
-        }
-        // ---- the adjoint levels first (they do not depend on H): A_{s+4} -> A_{s+3}, A_{s+2}, A_{s+1}, each parked in the thread's
-        // own LDS slot (sA[i] = A_{s+i+1}; nobody else reads it: no barrier for these)
-        v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};
-        sA[CK - 1][tid] = aq4;
-#pragma unroll 1
-        for (int l = CK - 1; l >= 1; --l) {
-            // A_t from A_{t+1}: P_k(p) = w'_k(p) A_{t+1}(p) goes to q = p + off_k; off_k = (+1,+1) (+1,0) (+1,-1) (0,+1) (0,-1) (-1,+1) (-1,0) (-1,-1).
-            // Column x' of the destination row takes P_k from column x' - dx_k of this row: dx = +1 -> the value one to the left.
-            v2f tdn[2], tup[2], mid[2];
-            auto send = [&](int k, v2f (&dst)[2], int dx, bool first) {
-                const v2f p0 = w[k][0] * a[0], p1 = w[k][1] * a[1];
-                v2f v0, v1;
-                if (dx > 0) { v0 = v2f{dpp_shr1(p1[1]), p0[0]}; v1 = v2f{p0[1], p1[0]}; }
-                else if (dx < 0) { v0 = v2f{p0[1], p1[0]}; v1 = v2f{p1[1], dpp_shl1(p0[0])}; }
-                else { v0 = p0; v1 = p1; }
-                dst[0] = first ? v0 : dst[0] + v0;
-                dst[1] = first ? v1 : dst[1] + v1;
-            };
-            send(0, tdn, 1, true); send(1, tdn, 0, false); send(2, tdn, -1, false);
-            send(3, mid, 1, true); send(4, mid, -1, false);
-            send(5, tup, 1, true); send(6, tup, 0, false); send(7, tup, -1, false);
-            sT[par][0][tid] = make_float4(tdn[0][0], tdn[0][1], tdn[1][0], tdn[1][1]);
-            sT[par][1][tid] = make_float4(tup[0][0], tup[0][1], tup[1][0], tup[1][1]);
+    // the whole segment loop, twice: blocks whose region lies inside the image (two thirds of them at KITTI size) need no
+    // "outside the image -> 0" selects
+    auto segments = [&](auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+    #pragma unroll 1
+        for (int j = 0; j < NSEG_RUN; ++j) {
+            float4 hq, aq4;   // H_s, A_{s+4} of the thread's group
+            if (PREFETCH) {
+                hq = nh;
+                aq4 = na;
+                if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
+            } else {
+                aq4 = seg_a(j);
+                hq = seg_h(j);   // (arrives under the three adjoint steps)
+            }
+            // ---- the adjoint levels first (they do not depend on H): A_{s+4} -> A_{s+3}, A_{s+2}, A_{s+1}, each parked in the thread's
+            // own LDS slot (sA[i] = A_{s+i+1}; nobody else reads it: no barrier for these)
+            v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};
+            sA[CK - 1][tid] = aq4;
+    #pragma unroll 1
+            for (int l = CK - 1; l >= 1; --l) {
+                // A_t from A_{t+1}: P_k(p) = w'_k(p) A_{t+1}(p) goes to q = p + off_k; off_k = (+1,+1) (+1,0) (+1,-1) (0,+1) (0,-1) (-1,+1) (-1,0) (-1,-1).
+                // Column x' of the destination row takes P_k from column x' - dx_k of this row: dx = +1 -> the value one to the left.
+                v2f tdn[2], tup[2], mid[2];
+                auto send = [&](int k, v2f (&dst)[2], int dx, bool first) {
+                    const v2f p0 = w[k][0] * a[0], p1 = w[k][1] * a[1];
+                    v2f v0, v1;
+                    if (dx > 0) { v0 = v2f{dpp_shr1(p1[1]), p0[0]}; v1 = v2f{p0[1], p1[0]}; }
+                    else if (dx < 0) { v0 = v2f{p0[1], p1[0]}; v1 = v2f{p1[1], dpp_shl1(p0[0])}; }
+                    else { v0 = p0; v1 = p1; }
+                    dst[0] = first ? v0 : dst[0] + v0;
+                    dst[1] = first ? v1 : dst[1] + v1;
+                };
+                send(0, tdn, 1, true); send(1, tdn, 0, false); send(2, tdn, -1, false);
+                send(3, mid, 1, true); send(4, mid, -1, false);
+                send(5, tup, 1, true); send(6, tup, 0, false); send(7, tup, -1, false);
+                sT[par][0][tid] = make_float4(tdn[0][0], tdn[0][1], tdn[1][0], tdn[1][1]);
+                sT[par][1][tid] = make_float4(tup[0][0], tup[0][1], tup[1][0], tup[1][1]);
+                lds_barrier();
+                const float4 fa = sT[par][0][tup_i];     // from the row above, sent down
+                const float4 fb = sT[par][1][tdn_i];     // from the row below, sent up
+                par ^= 1;
+                a[0] = mid[0] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y};
+                if (MASKED && !inimg) a[0] = zero2;
+                a[1] = mid[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w};
+                if (MASKED && !inimg) a[1] = zero2;
+                sA[l - 1][tid] = make_float4(a[0][0], a[0][1], a[1][0], a[1][1]);
+            }
+            // ---- then H_s -> H_{s+3}; the pixel pairs built for a step are also what A_{t+1} multiplies with for dW'
+            sH[0][tid] = hq;
             lds_barrier();
-            const float4 fa = sT[par][0][tup_i];     // from the row above, sent down
-            const float4 fb = sT[par][1][tdn_i];     // from the row below, sent up
-            par ^= 1;
-            a[0] = inimg ? mid[0] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y} : zero2;
-            a[1] = inimg ? mid[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w} : zero2;
-            sA[l - 1][tid] = make_float4(a[0][0], a[0][1], a[1][0], a[1][1]);
-        }
-        // ---- then H_s -> H_{s+3}; the pixel pairs built for a step are also what A_{t+1} multiplies with for dW'
-        sH[0][tid] = hq;
-        lds_barrier();
-#pragma unroll 1
-        for (int l = 0; l < CK; ++l) {
-            v2f hp[3][3][2];
-            rows_of(l & 1, hq, hp);
-            if (wave_in_tile_rows) {
-                const float4 aq = sA[l][tid];   // A_{s+l+1}
-                const v2f av[2] = {v2f{aq.x, aq.y}, v2f{aq.z, aq.w}};
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    dC[hlf] += av[hlf];
-                    dW[0][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][2][hlf], dW[0][hlf]); dW[1][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][1][hlf], dW[1][hlf]);
-                    dW[2][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][0][hlf], dW[2][hlf]); dW[3][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][2][hlf], dW[3][hlf]);
-                    dW[4][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][0][hlf], dW[4][hlf]); dW[5][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][2][hlf], dW[5][hlf]);
-                    dW[6][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][1][hlf], dW[6][hlf]); dW[7][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][0][hlf], dW[7][hlf]);
+    #pragma unroll 1
+            for (int l = 0; l < CK; ++l) {
+                v2f hp[3][3][2];
+                rows_of(l & 1, hq, hp);
+                if (wave_in_tile_rows) {
+                    const float4 aq = sA[l][tid];   // A_{s+l+1}
+                    const v2f av[2] = {v2f{aq.x, aq.y}, v2f{aq.z, aq.w}};
+    #pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        dC[hlf] += av[hlf];
+                        dW[0][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][2][hlf], dW[0][hlf]); dW[1][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][1][hlf], dW[1][hlf]);
+                        dW[2][hlf] = __builtin_elementwise_fma(av[hlf], hp[0][0][hlf], dW[2][hlf]); dW[3][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][2][hlf], dW[3][hlf]);
+                        dW[4][hlf] = __builtin_elementwise_fma(av[hlf], hp[1][0][hlf], dW[4][hlf]); dW[5][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][2][hlf], dW[5][hlf]);
+                        dW[6][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][1][hlf], dW[6][hlf]); dW[7][hlf] = __builtin_elementwise_fma(av[hlf], hp[2][0][hlf], dW[7][hlf]);
+                    }
                 }
+                if (l == CK - 1) break;
+                v2f n[2];
+    #pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    v2f t = cp[hlf];
+                    t = __builtin_elementwise_fma(w[0][hlf], hp[0][2][hlf], t); t = __builtin_elementwise_fma(w[1][hlf], hp[0][1][hlf], t);
+                    t = __builtin_elementwise_fma(w[2][hlf], hp[0][0][hlf], t); t = __builtin_elementwise_fma(w[3][hlf], hp[1][2][hlf], t);
+                    t = __builtin_elementwise_fma(w[4][hlf], hp[1][0][hlf], t); t = __builtin_elementwise_fma(w[5][hlf], hp[2][2][hlf], t);
+                    t = __builtin_elementwise_fma(w[6][hlf], hp[2][1][hlf], t); t = __builtin_elementwise_fma(w[7][hlf], hp[2][0][hlf], t);
+                    n[hlf] = (MASKED && !inimg) ? zero2 : t;
+                }
+                hq = make_float4(n[0][0], n[0][1], n[1][0], n[1][1]);
+                sH[(l + 1) & 1][tid] = hq;   // (the plane read two steps ago: everybody is past the barrier in between)
+                lds_barrier();
             }
-            if (l == CK - 1) break;
-            v2f n[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                v2f t = cp[hlf];
-                t = __builtin_elementwise_fma(w[0][hlf], hp[0][2][hlf], t); t = __builtin_elementwise_fma(w[1][hlf], hp[0][1][hlf], t);
-                t = __builtin_elementwise_fma(w[2][hlf], hp[0][0][hlf], t); t = __builtin_elementwise_fma(w[3][hlf], hp[1][2][hlf], t);
-                t = __builtin_elementwise_fma(w[4][hlf], hp[1][0][hlf], t); t = __builtin_elementwise_fma(w[5][hlf], hp[2][2][hlf], t);
-                t = __builtin_elementwise_fma(w[6][hlf], hp[2][1][hlf], t); t = __builtin_elementwise_fma(w[7][hlf], hp[2][0][hlf], t);
-                n[hlf] = inimg ? t : zero2;
-            }
-            hq = make_float4(n[0][0], n[0][1], n[1][0], n[1][1]);
-            sH[(l + 1) & 1][tid] = hq;   // (the plane read two steps ago: everybody is past the barrier in between)
-            lds_barrier();
         }
-    }
+    };
+    const int ry0 = (int)blockIdx.y * CK_TR - CK, xg0 = (int)blockIdx.x * CK_TG - 1;
+    if (ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4) segments(std::false_type{});
+    else segments(std::true_type{});
 #ifdef BWD_EXP_NOEPI
     if (dC[0][0] != 12345.f) return;
 #endif
@@ -632,29 +478,7 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     bwd_epilogue4(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
 }
 
-template <int RL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bwd_final4_kernel(const float* __restrict__ g, const float* __restrict__ blur,
-                                                          const float* __restrict__ sparse, const float* __restrict__ hh,
-                                                          const float* __restrict__ ah, const float* __restrict__ a0p,
-                                                          const float* __restrict__ gout, float* __restrict__ gg,
-                                                          float* __restrict__ gb, int B, int H, int W, int norm) {
-    bwd_final4_body<RL, 2>(g, blur, sparse, hh, ah, a0p, gout, gg, gb, B, H, W, norm);
-}
-
 }  // namespace
-
-// final pass of the assembly-sweep backward; CSPN_BWD_FINAL_RL=64 selects the one-row-per-wave mapping (A/B)
-static void launch_final4(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* a0,
-                          const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
-    static const bool rl64 = [] { const char* e = getenv("CSPN_BWD_FINAL_RL"); return e && atoi(e) == 64; }();
-    if (rl64) {
-        const int nbx = (W / 4 + 63) / 64, nby = (H + 3) / 4, ntile = nbx * nby * B, per = (ntile + 7) / 8;
-        hipLaunchKernelGGL(bwd_final4_kernel<64>, dim3(per * 8), dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm);
-    } else {
-        const dim3 grid((W / 4 + 15) / 16, (H + 15) / 16, B);
-        hipLaunchKernelGGL(bwd_final4_kernel<16>, grid, dim3(256), 0, st, g, blur, sparse, hh, ah, a0, gout, gg, gb, B, H, W, norm);
-    }
-}
 
 constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
                                      // one row up and one pixel left of its first row)
@@ -716,7 +540,7 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         hipLaunchKernelGGL(bwd_step_kernel, dim3(blocks), dim3(256), 0, st, wt,
                            t == n_iter - 1 ? gout : ah + (size_t)(t + 1) * total, ah + (size_t)t * total, B, H, W);
     if (int e = check_launch("bwd_step_kernel")) return e;
-    hipLaunchKernelGGL(bwd_final_kernel<false>, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, nullptr, gout, gg, gb, B,
+    hipLaunchKernelGGL(bwd_final_kernel, dim3(blocks), dim3(256), 0, st, g, blur, sparse, hh, ah, gout, gg, gb, B,
                        H, W, n_iter, norm);
     return check_launch("bwd_final_kernel");
 }

@@ -101,8 +101,8 @@ int cspn2d_backward_f32(const float* guidance, const float* blur, const float* s
                         float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
-/* Training mode (optional, faster): the forward also keeps what the backward needs -- every intermediate level H_1..H_23 and
- * the folded coefficients, cspn2d_history_bytes() bytes, 256-B aligned; 0 = not available for this shape / n_iter (then use
+/* Training mode (optional, faster): the forward also keeps what the backward needs -- every fourth intermediate level (H_4, H_8 ..
+ * H_20; the backward recomputes the three in between) and the folded coefficients, 13 planes of B*H*W floats, cspn2d_history_bytes() bytes, 256-B aligned; 0 = not available for this shape / n_iter (then use
  * cspn2d_forward_f32 + cspn2d_backward_f32, which recomputes the history).  This is what torch autograd does for the
  * reference by saving ~27 temporaries per iteration.
  *   cspn2d_forward_history_f32: same result as cspn2d_forward_f32, plus `history`; workspace cspn2d_workspace_bytes().

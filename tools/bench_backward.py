@@ -88,8 +88,9 @@ def main():
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
                       "train_step_fwd_bwd_ms": train,
-                      "note": "forward and adjoint sweeps each as one launch of the fused ring kernel writing its 23 intermediate "
-                              "levels (the forward one also the folded coefficients), + the final pass; workspace 56 planes + the row-descriptor table"}))
+                      "note": "forward and adjoint sweeps each as one launch of the fused ring kernel keeping every fourth of its levels "
+                              "(the forward one also the folded coefficients), + the final pass that recomputes the levels in between "
+                              "tile by tile; workspace 20 planes"}))
 
 
 if __name__ == "__main__":
