@@ -59,7 +59,7 @@ def test_argument_errors_are_reported_without_gpu():
 def test_backward_and_aux_argument_errors_are_reported_without_gpu():
     lib = cspn_amd.load()
     fake = ctypes.c_void_p(4096)
-    assert lib.cspn2d_backward_workspace_bytes(2, 64, 320, 24) >= (23 + 23) * 2 * 64 * 320 * 4   # two level histories
+    assert lib.cspn2d_backward_workspace_bytes(2, 64, 320, 24) >= (5 + 8 + 5 + 2) * 2 * 64 * 320 * 4   # checkpoints of both sweeps, coefficients, A_0, a scratch output
     assert lib.cspn2d_backward_workspace_bytes(2, 9, 10, 5) >= (4 + 5) * 2 * 9 * 10 * 4
     assert lib.cspn2d_backward_workspace_bytes(1, 4, 4, 0) == 0
     rc = lib.cspn2d_backward_f32(fake, fake, None, None, fake, fake, 1, 4, 4, 3, 0, None, 0, None)
