@@ -66,7 +66,10 @@ def test_hip_backward_vs_reference_autograd_goldens():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,N,norm,sp", [(2, 37, 53, 24, "8sum", True), (1, 64, 320, 24, "8sum_abs", True),
                                              (3, 20, 256, 12, "8sum", False), (1, 5, 9, 1, "8sum_abs", False),
-                                             (1, 30, 40, 30, "8sum", True)])
+                                             (1, 30, 40, 30, "8sum", True),
+                                             # the checkpointed final pass at awkward tile geometry: one tile row and a bit, a last
+                                             # tile column of 8 pixels, image borders inside every block
+                                             (2, 41, 260, 24, "8sum", True), (1, 89, 300, 24, "8sum_abs", False)])
 def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
     import cspn_amd
     g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp)
@@ -162,3 +165,33 @@ def test_forward_and_backward_vs_stock_torch_autograd_at_full_width():
     assert _err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-4
     assert _check(g1.grad.cpu().numpy(), g0.grad.cpu().numpy())
     assert _check(h1.grad.cpu().numpy(), h0.grad.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sp", [False, True])
+def test_backward_norm_none_on_the_checkpointed_path_vs_torch_autograd(sp):
+    """norm NONE (gates used as given, centre-sited: the Paddle-style 2D contract; c' = m H_0 in the recomputing final pass) at a
+    size the assembly sweeps take, against torch autograd through the same recurrence"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.torch_path import _gather8
+    import cspn_amd
+    B, H, W, N = 2, 50, 272, 24
+    gen = torch.Generator().manual_seed(17)
+    g = torch.rand(B, 8, H, W, generator=gen)
+    g = (g / g.sum(1, keepdim=True)).cuda()
+    h = (torch.rand(B, 1, H, W, generator=gen) * 10).cuda()
+    s = ((torch.rand(B, 1, H, W, generator=gen) < 0.02).float() * 3.0).cuda() if sp else None
+    go = torch.randn(B, 1, H, W, generator=gen).cuda()
+    g0, h0 = g.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    cur = h0
+    for _ in range(N):
+        cur = (g0 * _gather8(cur)).sum(1, keepdim=True)
+        if s is not None:
+            m = s.sign()
+            cur = (1 - m) * cur + m * h0
+    cur.backward(go)
+    gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, N, "none")
+    assert _check(gg.cpu().numpy(), g0.grad.cpu().numpy())
+    assert _check(gh.cpu().numpy(), h0.grad.cpu().numpy())
