@@ -198,9 +198,8 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
         }
         return;
     }
-    // Two passes over the eight planes (the second re-reads its 4-column runs from cache) instead of keeping G, the raw values
-    // and dL/dw of all planes in registers: the kernel has to stay at 4+ waves per SIMD to hide its loads.
-    // G_k(p) = g~_k(p + off_k): a run of four columns of plane k in row y + dy_k starting at x + dx_k, zero outside the image
+    // G_k(p) = g~_k(p + off_k): a run of four columns of plane k in row y + dy_k starting at x + dx_k, zero outside the image; the
+    // eight runs stay in registers for the second half (the coefficient registers of the level loop are free by now)
     auto run = [&](int k, float (&v)[4]) -> bool {
         const int yy = y + dy2(k), xs = x + dx2(k);
         v[0] = v[1] = v[2] = v[3] = 0.f;
@@ -219,14 +218,15 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     float om[4], ch[4], S[4] = {0.f, 0.f, 0.f, 0.f}, T1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+    float vk[8][4];
+    bool rowin[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float v[4];
-        run(k, v);
+        rowin[k] = run(k, vk[k]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
-            S[i] += fabsf(v[i]);
+            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(vk[k][i]) : vk[k][i];
+            S[i] += fabsf(vk[k][i]);
             gs[i] += G;
             T1[i] = fmaf(om[i] * (dW[k][i] - ch[i]), G, T1[i]);
         }
@@ -256,8 +256,8 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float v[4];
-            if (!run(k, v)) continue;  // the zero padding is a constant
+            const float (&v)[4] = vk[k];
+            if (!rowin[k]) continue;  // the zero padding is a constant
             const int yy = y + dy2(k), xs = x + dx2(k);
             float d[4];
 #pragma unroll
@@ -304,10 +304,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // segment's checkpoints that are meant to arrive under this segment's arithmetic
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// CK_ROWS = region rows: 48 (one block of 768 threads per CU, three waves per SIMD, the next segment's checkpoints prefetched) or
-// 32 (two blocks of 512 threads per CU, four waves per SIMD = 128 registers: no prefetch, the other block covers the loads)
+// CK_ROWS = region rows: 48 (one block of 768 threads per CU, three waves per SIMD).  Measured alternatives
+// (profiles/r03_backward_checkpoints.md): 24 and 32 rows with two blocks per CU, 64 rows with 1024 threads -- all slower.
 template <int CK_ROWS>
-__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(CK_ROWS == 32 ? 4 : 3, CK_ROWS == 32 ? 4 : 3))) void bwd_final_ck_kernel(
+__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_final_ck_kernel(
     const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
     const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
     float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     auto seg_h = [&](int j) { return j == 0 ? ld(blur) : reg_to_img(ld(hh + (size_t)(j - 1) * total)); };            // H_{4j}
     auto seg_a = [&](int j) { return j == NSEG - 1 ? ld(gout) : reg_to_img(ld(ah + (size_t)(NSEG - 2 - j) * total)); };   // A_{4j+4}
     const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;   // a wave = 4 region rows: the first / last wave only feeds
-    constexpr bool PREFETCH = CK_ROWS == 48;
+    constexpr bool PREFETCH = true;   // the next segment's checkpoints are requested one segment ahead
     float4 nh = z4, na = z4;
     if (PREFETCH) { nh = seg_h(0); na = seg_a(0); }
     int par = 0;
@@ -494,17 +494,12 @@ size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
-// final pass of the assembly-sweep backward: from the checkpoints of both sweeps (CSPN_BWD_CK_ROWS=24|48: region rows, A/B)
+// final pass of the assembly-sweep backward: from the checkpoints of both sweeps
 static void launch_final_ck(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* wf,
                             const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
-    static const int rows = [] { const char* e = getenv("CSPN_BWD_CK_ROWS"); return e ? atoi(e) : 48; }();
-    const unsigned nbx = (unsigned)((W / 4 + CK_TG - 1) / CK_TG);
-    if (rows == 48)
-        hipLaunchKernelGGL(bwd_final_ck_kernel<48>, dim3(nbx, (H + 39) / 40, B), dim3(48 * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
-                           gg, gb, B, H, W, norm);
-    else
-        hipLaunchKernelGGL(bwd_final_ck_kernel<32>, dim3(nbx, (H + 23) / 24, B), dim3(32 * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
-                           gg, gb, B, H, W, norm);
+    constexpr int ROWS = 48, TROWS = ROWS - 2 * CK;
+    hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)((W / 4 + CK_TG - 1) / CK_TG), (unsigned)((H + TROWS - 1) / TROWS), B),
+                       dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm);
 }
 
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,

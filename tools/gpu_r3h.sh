@@ -2,7 +2,7 @@
 # round 3: 2D backward from checkpoints (every 4th level kept, the rest recomputed by bwd_final_ck_kernel) -- tests, timing, kernel stats
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONPATH=$PWD:$PWD/tests
-for rows in ${CK_ROWS_LIST:-24 48}; do
+for rows in ${CK_ROWS_LIST:-48}; do
 export CSPN_BWD_CK_ROWS=$rows
 echo "== region rows $rows"
 timeout 900 python -m pytest tests/test_backward.py tests/test_dropin_host.py -m gpu -x -q 2>&1 | tail -${TAILN:-3}
