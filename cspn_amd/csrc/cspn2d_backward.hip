@@ -324,7 +324,14 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     const size_t HW = (size_t)H * W, total = (size_t)B * HW;
     const size_t idx = (size_t)b * HW + (size_t)(inimg ? y : 0) * W + x;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld = [&](const float* p) { return inimg ? *reinterpret_cast<const float4*>(p + idx) : z4; };
+    // (idx is a valid group of its row even for threads outside the image -- clamped above --: load unconditionally, select the value.
+    // A conditional load through this lambda had been compiled to four FLAT dword loads, which also tie up lgkmcnt, the counter
+    // every LDS barrier below waits on)
+    auto ld = [&](const float* p) {
+        typedef float v4g __attribute__((ext_vector_type(4)));
+        const v4g v = *(const __attribute__((address_space(1))) v4g*)(p + idx);   // one global_load_dwordx4
+        return inimg ? make_float4(v.x, v.y, v.z, v.w) : z4;
+    };
     // the thread's own coefficients and constant term; the arithmetic below runs on pixel pairs (v_pk_fma_f32 / v_pk_mul_f32 /
     // v_pk_add_f32: the pass is bound by VALU issue, not by memory)
     v2f w[8][2], cp[2];
