@@ -376,12 +376,12 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
         }
     };
     // tap k multiplies with row d = (0,0,0,1,1,2,2,2)[k], column offset o = (2,1,0,2,0,2,1,0)[k]
-    auto seg_h = [&](int j) { return j == 0 ? ld(blur) : reg_to_img(ld(hh + (size_t)(j - 1) * total)); };            // H_{4j}
-    auto seg_a = [&](int j) { return j == NSEG - 1 ? ld(gout) : reg_to_img(ld(ah + (size_t)(NSEG - 2 - j) * total)); };   // A_{4j+4}
+    // raw quads (the sweeps' planes are in register order, blur / dL/dout in image order): reordered when they are USED, so that a
+    // prefetched quad is not waited for at the point of the request
+    auto seg_h = [&](int j) { return ld(j == 0 ? blur : hh + (size_t)(j - 1) * total); };                       // H_{4j}
+    auto seg_a = [&](int j) { return ld(j == NSEG - 1 ? gout : ah + (size_t)(NSEG - 2 - j) * total); };         // A_{4j+4}
     const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;   // a wave = 4 region rows: the first / last wave only feeds
-    constexpr bool PREFETCH = true;   // the next segment's checkpoints are requested one segment ahead
-    float4 nh = z4, na = z4;
-    if (PREFETCH) { nh = seg_h(0); na = seg_a(0); }
+    float4 nh = seg_h(0), na = seg_a(0);   // the checkpoints are requested one segment ahead
     int par = 0;
 #ifdef BWD_EXP_NOLOOP
     constexpr int NSEG_RUN = 0;
@@ -395,14 +395,9 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     #pragma unroll 1
         for (int j = 0; j < NSEG_RUN; ++j) {
             float4 hq, aq4;   // H_s, A_{s+4} of the thread's group
-            if (PREFETCH) {
-                hq = nh;
-                aq4 = na;
-                if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
-            } else {
-                aq4 = seg_a(j);
-                hq = seg_h(j);   // (arrives under the three adjoint steps)
-            }
+            hq = j == 0 ? nh : reg_to_img(nh);
+            aq4 = j == NSEG - 1 ? na : reg_to_img(na);
+            if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }   // the next segment's checkpoints arrive under this one's arithmetic
             // ---- the adjoint levels first (they do not depend on H): A_{s+4} -> A_{s+3}, A_{s+2}, A_{s+1}, each parked in the thread's
             // own LDS slot (sA[i] = A_{s+i+1}; nobody else reads it: no barrier for these)
             v2f a[2] = {v2f{aq4.x, aq4.y}, v2f{aq4.z, aq4.w}};
