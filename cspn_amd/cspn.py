@@ -62,7 +62,7 @@ class Affinity_Propagate(nn.Module):
         self.in_feature = 1
         self.out_feature = 1
         self.algo = "auto"
-        self.keep_history = True   # training: keep the forward's level history for the backward
+        self.keep_history = True   # training: keep the forward's checkpoints (every fourth level + folded coefficients) for the backward
 
     def forward(self, guidance, blur_depth, sparse_depth=None, n_iter=None):
         n = self.prop_time if n_iter is None else int(n_iter)

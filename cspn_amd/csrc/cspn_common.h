@@ -77,7 +77,8 @@ int tsw2d_adjoint_pass(const float* wf, const float* a_in, float* a0, int B, int
 size_t backward2d_workspace(int B, int H, int W, int n_iter);
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
                int W, int n_iter, int norm, void* ws, hipStream_t st);
-// training mode: the forward keeps its level history (24-iteration passes the assembly kernel takes), the backward starts there
+// training mode: the forward keeps its checkpoints (every fourth level + the folded coefficients; 24-iteration passes the assembly
+// kernel takes), the backward starts there
 size_t history2d_bytes(int B, int H, int W, int n_iter);  // 0: not available for this shape
 int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
                       int norm, void* ws, hipStream_t st);

@@ -110,7 +110,7 @@ def cspn2d_backward(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, nor
 
 
 def cspn2d_history_bytes(B, H, W, n_iter):
-    """bytes of the level history the training-mode forward keeps for its backward (0: not available for this shape)"""
+    """bytes of what the training-mode forward keeps for its backward: every fourth level + the folded coefficients (0: not available for this shape)"""
     return int(_lib.load().cspn2d_history_bytes(int(B), int(H), int(W), int(n_iter)))
 
 

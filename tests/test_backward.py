@@ -90,7 +90,7 @@ def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm,sp", [("8sum", True), ("8sum_abs", False)])
 def test_training_mode_history_matches_recompute_path(norm, sp):
-    """the forward that keeps its level history + the backward that starts from it == plain forward + recomputing backward"""
+    """the forward that keeps its checkpoints + the backward that starts from them == plain forward + recomputing backward"""
     import cspn_amd
     B, H, W, N = 3, 70, 512, 24
     assert cspn_amd.cspn2d_history_bytes(B, H, W, N) > 0 and cspn_amd.cspn2d_history_bytes(B, H, 64, N) == 0
