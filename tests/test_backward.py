@@ -69,7 +69,8 @@ def test_hip_backward_vs_reference_autograd_goldens():
                                              (1, 30, 40, 30, "8sum", True),
                                              # the checkpointed final pass at awkward tile geometry: one tile row and a bit, a last
                                              # tile column of 8 pixels, image borders inside every block
-                                             (2, 41, 260, 24, "8sum", True), (1, 89, 300, 24, "8sum_abs", False)])
+                                             (2, 41, 260, 24, "8sum", True), (1, 89, 300, 24, "8sum_abs", False),
+                                             (1, 3, 256, 24, "8sum", False)])   # an image lower than the recompute halo
 def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
     import cspn_amd
     g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp)
