@@ -171,6 +171,8 @@ __device__ __forceinline__ void st4u(float* p, float4 v) { __builtin_memcpy(p, &
 
 // ---- the end of the final pass for one group of 4 columns (b, y, x .. x + 3): from dW'_k and dC through the fold,
 // the normalisation and the neighbour-sited gather to dL/dguidance and dL/dblur_depth (see the file header)
+// INTERIOR: every run (row y - 1 .. y + 1, columns x - 1 .. x + 4) lies inside the image -- no bounds checks, no border zero fill
+template <bool INTERIOR>
 __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse,
                                               const float* __restrict__ a0p, float* __restrict__ gg, float* __restrict__ gb, int b, int y,
                                               int x, size_t idx, size_t HW, int H, int W, int norm, const float (&dW)[8][4],
@@ -203,9 +205,9 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     auto run = [&](int k, float (&v)[4]) -> bool {
         const int yy = y + dy2(k), xs = x + dx2(k);
         v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (yy < 0 || yy >= H) return false;
+        if (!INTERIOR && (yy < 0 || yy >= H)) return false;
         const float* src = gbp + k * HW + (size_t)yy * W;
-        if (xs >= 0 && xs + 3 < W) {
+        if (INTERIOR || (xs >= 0 && xs + 3 < W)) {
             const float4 q = ld4u(src + xs);
             v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         } else {
@@ -243,7 +245,7 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     if (ggp) {
         // g_k(q) with q - off_k outside the image is read by no pixel (the gather sees the zero padding instead): gradient 0
         // (only groups on the image's border have such elements)
-        if (y == 0 || y == H - 1 || x == 0 || x + 4 >= W) {
+        if (!INTERIOR && (y == 0 || y == H - 1 || x == 0 || x + 4 >= W)) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int ys = y - dy2(k);
@@ -269,7 +271,7 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
                 d[i] = r;
             }
             float* dst = ggp + k * HW + (size_t)yy * W;   // g_k(p + off_k) is read by pixel p only
-            if (xs >= 0 && xs + 3 < W) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
+            if (INTERIOR || (xs >= 0 && xs + 3 < W)) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
             else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -468,7 +470,8 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
         }
     };
     const int ry0 = (int)blockIdx.y * CK_TR - CK, xg0 = (int)blockIdx.x * CK_TG - 1;
-    if (ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4) segments(std::false_type{});
+    const bool blk_in = ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4;
+    if (blk_in) segments(std::false_type{});
     else segments(std::true_type{});
 #ifdef BWD_EXP_NOEPI
     if (dC[0][0] != 12345.f) return;
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     float dWs[8][4], dCs[4] = {dC[0][0], dC[0][1], dC[1][0], dC[1][1]};
 #pragma unroll
     for (int k = 0; k < 8; ++k) { dWs[k][0] = dW[k][0][0]; dWs[k][1] = dW[k][0][1]; dWs[k][2] = dW[k][1][0]; dWs[k][3] = dW[k][1][1]; }
-    bwd_epilogue4(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+    if (blk_in) bwd_epilogue4<true>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+    else bwd_epilogue4<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
 }
 
 }  // namespace
