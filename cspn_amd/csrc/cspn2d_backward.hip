@@ -318,8 +318,14 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     __shared__ __attribute__((aligned(16))) float4 sA[CK][CK_NT];      // A_{s+1} .. A_{s+4}: every thread's own group only
     __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
     const int tid = threadIdx.x, gx = tid & (CK_GR - 1), ry = tid >> 4;
-    const int W4 = W >> 2, b = blockIdx.z;
-    const int y = (int)blockIdx.y * CK_TR - CK + ry, xg = (int)blockIdx.x * CK_TG - 1 + gx;
+    const int W4 = W >> 2;
+    // 1-D grid; the hardware deals block i to XCD i % 8: every XCD gets a contiguous run of tiles (numbered along x, then y, then
+    // the batch), so that the tiles whose regions overlap run on the same XCD at about the same time and share its L2
+    const int nbx = (W4 + CK_TG - 1) / CK_TG, nby = (H + CK_TR - 1) / CK_TR, ntile = nbx * nby * B, per = (ntile + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= ntile || (int)(blockIdx.x >> 3) >= per) return;   // (whole block: no barrier is left waiting)
+    const int bx = tile % nbx, by = (tile / nbx) % nby, b = tile / (nbx * nby);
+    const int y = by * CK_TR - CK + ry, xg = bx * CK_TG - 1 + gx;
     const bool inimg = y >= 0 && y < H && xg >= 0 && xg < W4;
     const bool intile = inimg && ry >= CK && ry < CK_ROWS - CK && gx >= 1 && gx < CK_GR - 1;
     const int x = 4 * (inimg ? xg : 0);
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
             }
         }
     };
-    const int ry0 = (int)blockIdx.y * CK_TR - CK, xg0 = (int)blockIdx.x * CK_TG - 1;
+    const int ry0 = by * CK_TR - CK, xg0 = bx * CK_TG - 1;
     const bool blk_in = ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4;
     if (blk_in) segments(std::false_type{});
     else segments(std::true_type{});
@@ -504,8 +510,9 @@ size_t backward2d_workspace(int B, int H, int W, int n_iter) {
 static void launch_final_ck(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* wf,
                             const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
     constexpr int ROWS = 48, TROWS = ROWS - 2 * CK;
-    hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)((W / 4 + CK_TG - 1) / CK_TG), (unsigned)((H + TROWS - 1) / TROWS), B),
-                       dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm);
+    const int ntile = ((W / 4 + CK_TG - 1) / CK_TG) * ((H + TROWS - 1) / TROWS) * B, per = (ntile + 7) / 8;
+    hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
+                       gg, gb, B, H, W, norm);
 }
 
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
