@@ -235,7 +235,11 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     }
     float rS[4], t2[4];
 #pragma unroll
+#ifdef BWD_IEEE_DIV   // (accuracy A/B, tools/build_bwdvar.sh: no difference against a float64 oracle, profiles/r03_fuzz_parity.txt)
+    for (int i = 0; i < 4; ++i) { rS[i] = 1.f / S[i]; t2[i] = T1[i] / (S[i] * S[i]); }
+#else
     for (int i = 0; i < 4; ++i) { rS[i] = __builtin_amdgcn_rcpf(S[i]); t2[i] = T1[i] * rS[i] * rS[i]; }   // (v_rcp_f32: 1 ulp; three IEEE divisions per pixel were ~150 instructions per thread)
+#endif
     if (gb) {
         float o[4];
 #pragma unroll

@@ -51,7 +51,10 @@ for case in range(int(os.environ.get("FUZZ_CASES", "40"))):
         for a_, r_ in ((gg, g0.grad), (gh, h0.grad)):
             fin = torch.isfinite(r_)
             assert torch.equal(torch.isfinite(a_), fin), ("2D bwd finite", B, H, W, norm, sp)
-            tol = 5e-6 * float(r_[fin].abs().max()) + 2e-4 * r_[fin].abs()
+            # both sides are fp32: dG = dw / S - sign(G) T1 / S^2 cancels where S is small, which amplifies the rounding of either
+            # (against a float64 oracle the worst element of such a case was 7.7e-6 of max|grad| for this path and 4.1e-6 for torch
+            # itself, tools/fuzz_case22.py): the floor is the sum of the two noises
+            tol = 2e-5 * float(r_[fin].abs().max()) + 2e-4 * r_[fin].abs()
             assert bool(((a_[fin] - r_[fin]).abs() <= tol).all()), ("2D bwd", B, H, W, norm, sp, float((a_[fin] - r_[fin]).abs().max()))
         nb2 += 1
     # ---- 3D
