@@ -66,6 +66,11 @@ def parse():
                     help="profiling runs: one torch elementwise kernel over the depth batch before the loop (known byte count, "
                          "calibrates FETCH_SIZE / WRITE_SIZE in the same rocprofv3 trace)")
     ap.add_argument("--no-broadcast", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N > 1, weak scaling: do not also time BASELINE config 3 as written (--global-batch images sharded over the ranks)")
+    ap.add_argument("--plan-mode", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="A/B measurements only (through the hook library, not the ABI): 1 = the linear plan without XCD-aware placement, "
+                         "2 = the band-group plan of rounds 1-3, 3 = the round-3 loop (experiment builds); 0 = the product (the ABI call)")
     ap.add_argument("--layout", default="planar", choices=["planar", "sited8"],
                     help="sited8: A/B experiment (DESIGN.md 3.6) -- the guidance is converted ONCE, outside the timed region, to the "
                          "producer-side [B,H,W/2,8,2] layout and the timed step is cspn2d_forward_sited8_f32")
@@ -250,6 +255,121 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
         dist.destroy_process_group()
 
 
+def _reduce(dist, vals, op, dev, shared_gpu, notes):
+    """all_reduce a few float64 values; a failing collective must not cost the throughput line: rank 0 then reports its own
+    numbers and says so (`notes`)"""
+    if dist is None:
+        return list(vals)
+    try:
+        t = torch.tensor(list(vals), device="cpu" if shared_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return [float(x) for x in t]
+    except Exception as ex:   # noqa: BLE001 -- reported, never swallowed silently
+        notes.append("all_reduce failed (%s: %s): rank-0 values reported" % (type(ex).__name__, str(ex)[:200]))
+        return list(vals)
+
+
+def _barrier(dist, notes):
+    if dist is None:
+        return
+    try:
+        dist.barrier()
+    except Exception as ex:   # noqa: BLE001
+        notes.append("barrier failed (%s: %s)" % (type(ex).__name__, str(ex)[:200]))
+
+
+def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, warmup, prewarm_s, notes, parity=True):
+    """One timed leg of the 2D hot path: `steps` forwards over this rank's batch, bracketed by barrier + synchronize on both sides
+    (max over ranks), per-launch device time from HIP events on the launch stream.  scaling 'weak': --batch-per-gpu images on
+    every rank; 'strong': --global-batch images sharded (BASELINE config 3 as written)."""
+    H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
+    if scaling == "strong":
+        from cspn_amd.dist import shard_range
+        first, last = shard_range(a.global_batch, rank, world)
+        B = last - first
+        if B <= 0:
+            raise SystemExit("--scaling strong: --global-batch %d leaves rank %d of %d without an image" % (a.global_batch, rank, world))
+    else:
+        B, first = a.batch_per_gpu, rank * a.batch_per_gpu
+    g, h, s = synth(B, H, W, scale, sparse, dev, first=first)
+    algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
+    algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
+    norm = _lib.NORM_TYPES[a.norm_type]
+    ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(h)
+    stream = torch.cuda.current_stream(dev)
+
+    g8 = None
+    if a.layout == "sited8":
+        import cspn_amd
+        g8 = cspn_amd.guidance_to_sited8(g, a.norm_type)
+        torch.cuda.synchronize()
+    hooks = _lib.load_hooks() if a.plan_mode else None
+
+    def step():
+        if hooks is not None:
+            rc = hooks.cspn_debug_forward2d_plan(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                                 B, H, W, n_iter, norm, a.plan_mode, ws.data_ptr(), stream.cuda_stream)
+        elif g8 is not None:
+            rc = lib.cspn2d_forward_sited8_f32(g8.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                               B, H, W, n_iter, norm, stream.cuda_stream)
+        else:
+            rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
+                                             out.data_ptr(), B, H, W, n_iter, norm, algo_id, ws.data_ptr(), ws_bytes,
+                                             stream.cuda_stream)
+        _lib.check(rc, "cspn2d_forward")
+
+    if a.pmc_calib:
+        _calib = h * 1.0   # reads and writes B*H*W*4 bytes
+        del _calib
+    # clock pre-warm: untimed full-work launches for a fixed wall time (outside the timed region)
+    prewarm_done, prewarm_launches = 0.0, 0
+    if prewarm_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < prewarm_s:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            prewarm_launches += 50
+        prewarm_done = time.perf_counter() - t0
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    _barrier(dist, notes)
+    torch.cuda.synchronize()
+    # per-launch device time: HIP events on the stream the kernels are launched on
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    _barrier(dist, notes)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    par = None
+    if parity:
+        par = parity_check(out, g, h, s, n_iter, a.norm_type)
+        if dist is not None:
+            par["all_ranks_ok"] = bool(_reduce(dist, [1.0 if par["ok"] else 0.0], dist.ReduceOp.MIN, dev, shared_gpu, notes)[0] == 1.0)
+    elapsed, dev_ms_avg = _reduce(dist, [elapsed, dev_ms_avg], dist.ReduceOp.MAX if dist is not None else None, dev, shared_gpu, notes)
+    total_images = B * world
+    if dist is not None and scaling == "strong":
+        total_images = int(_reduce(dist, [float(B)], dist.ReduceOp.SUM, dev, shared_gpu, notes)[0])
+        if total_images == B and world > 1:   # (the reduction failed: the shards are a.global_batch in total by construction)
+            total_images = a.global_batch
+    bytes_per_px = 44 if sparse else 40  # SURVEY.md 8(d): guidance 32 + blur 4 (+ sparse 4) + out 4
+    alg_bytes = B * H * W * bytes_per_px  # per launch (one forward = all n_iter iterations), per GPU
+    return {"B": B, "H": H, "W": W, "n_iter": n_iter, "sparse": sparse, "scale": scale, "desc": desc, "algo_name": algo_name,
+            "elapsed": elapsed, "dev_ms_avg": dev_ms_avg, "dev_ms_min": dev_ms[0], "parity": par, "total_images": total_images,
+            "value": total_images * H * W * n_iter * steps / 1e6 / elapsed, "alg_bytes": alg_bytes,
+            "achieved": alg_bytes / (dev_ms_avg * 1e-3) / 1e9, "prewarm_s": prewarm_done, "prewarm_launches": prewarm_launches}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,122 +390,58 @@ def main():
     lib = cspn_amd.load()
 
     dist = None
-    broadcast_ms = None
+    notes = []
+    broadcast_ms, broadcast_error, backend = None, None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_gpu:  # RCCL refuses two ranks on one device; gloo keeps the control flow identical
+        backend = "gloo" if shared_gpu else "nccl"   # RCCL refuses two ranks on one device; gloo keeps the control flow identical
+        # every rank says where it is BEFORE the first collective: if the rendezvous or RCCL hangs or dies, this is in the log
+        sys.stderr.write("[bench.py rank %d/%d] device %d of %d: %s, backend %s (%s), broadcast %s bytes, HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (
+            rank, world, dev_index, ndev, torch.cuda.get_device_name(dev_index), backend, "RCCL over xGMI" if backend == "nccl" else "CPU",
+            "none" if (a.no_broadcast or shared_gpu) else str(BACKBONE_PARAMS * 4), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+        sys.stderr.flush()
+        if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if not a.no_broadcast and not shared_gpu:
-            from cspn_amd.dist import broadcast_flat_
-            buf = torch.empty(BACKBONE_PARAMS, dtype=torch.float32, device=dev).normal_()
-            broadcast_flat_([buf[:1024]])  # communicator warm-up
-            torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            dist.broadcast(buf, src=0)
-            torch.cuda.synchronize()
-            broadcast_ms = (time.perf_counter() - t0) * 1e3
-            del buf
+            # the one collective of the path (weights of the affinity backbone, once).  It is not part of the timed region: if it
+            # fails, the throughput line is still printed, with "broadcast_ms": null and the error
+            try:
+                from cspn_amd.dist import broadcast_flat_
+                buf = torch.empty(BACKBONE_PARAMS, dtype=torch.float32, device=dev).normal_()
+                broadcast_flat_([buf[:1024]])  # communicator warm-up
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                dist.broadcast(buf, src=0)
+                torch.cuda.synchronize()
+                broadcast_ms = (time.perf_counter() - t0) * 1e3
+                del buf
+            except Exception as ex:   # noqa: BLE001
+                broadcast_error = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+                sys.stderr.write("[bench.py rank %d] broadcast failed: %s\n" % (rank, broadcast_error))
 
     if a.workload == "vol3d":
         return run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu)
-    H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
-    if a.scaling == "strong":
-        from cspn_amd.dist import shard_range
-        first, last = shard_range(a.global_batch, rank, world)
-        B = last - first
-        if B <= 0:
-            raise SystemExit("--scaling strong: --global-batch %d leaves rank %d of %d without an image" % (a.global_batch, rank, world))
-    else:
-        B, first = a.batch_per_gpu, rank * a.batch_per_gpu
-    g, h, s = synth(B, H, W, scale, sparse, dev, first=first)
-    algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
-    algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
-    norm = _lib.NORM_TYPES[a.norm_type]
-    ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    out = torch.empty_like(h)
-    stream = torch.cuda.current_stream(dev)
-
-    g8 = None
-    if a.layout == "sited8":
-        g8 = cspn_amd.guidance_to_sited8(g, a.norm_type)
-        torch.cuda.synchronize()
-
-    def step():
-        if g8 is not None:
-            rc = lib.cspn2d_forward_sited8_f32(g8.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
-                                               B, H, W, n_iter, norm, stream.cuda_stream)
-        else:
-            rc = lib.cspn2d_forward_f32_algo(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None,
-                                             out.data_ptr(), B, H, W, n_iter, norm, algo_id, ws.data_ptr(), ws_bytes,
-                                             stream.cuda_stream)
-        _lib.check(rc, "cspn2d_forward")
-
-    if a.pmc_calib:
-        _calib = h * 1.0   # reads and writes B*H*W*4 bytes
-        del _calib
-    # clock pre-warm: untimed full-work launches for a fixed wall time (outside the timed region)
-    prewarm_s, prewarm_launches = 0.0, 0
-    if a.prewarm_s > 0:
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < a.prewarm_s:
-            for _ in range(50):
-                step()
-            torch.cuda.synchronize()
-            prewarm_launches += 50
-        prewarm_s = time.perf_counter() - t0
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # per-launch device time: HIP events on the stream the kernels are launched on
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
-        step()
-        e1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    dev_ms_avg = sum(dev_ms) / len(dev_ms)
-    parity = None
-    if not a.no_parity_check:
-        parity = parity_check(out, g, h, s, n_iter, a.norm_type)
-        if dist is not None:
-            ok = torch.tensor([1.0 if parity["ok"] else 0.0], device="cpu" if shared_gpu else dev, dtype=torch.float64)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            parity["all_ranks_ok"] = bool(ok.item() == 1.0)
-
-    if dist is not None:
-        t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms_avg = float(t[0]), float(t[1])
-
-    total_images = B * world
-    if dist is not None and a.scaling == "strong":
-        nb = torch.tensor([float(B)], device="cpu" if shared_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
-        total_images = int(nb.item())
+    m = measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, a.scaling, a.steps, a.warmup, a.prewarm_s, notes,
+                  parity=not a.no_parity_check)
+    # N > 1, weak scaling (the driver's command): BASELINE config 3 as written is the STRONG shape (batch 64 sharded over the GPUs),
+    # so the same run also times that and reports it under "strong" (same K / W, same barriers, outside the first timed region)
+    strong = None
+    if world > 1 and a.scaling == "weak" and not a.no_strong_leg:
+        try:
+            strong = measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, "strong", a.steps, a.warmup, min(a.prewarm_s, 0.3), notes,
+                               parity=not a.no_parity_check)
+        except SystemExit as ex:
+            notes.append("strong leg skipped: %s" % ex)
     if rank == 0:
-        px = B * H * W
-        total_mpix_iters = total_images * H * W * n_iter * a.steps / 1e6
-        value = total_mpix_iters / elapsed
-        bytes_per_px = 44 if sparse else 40  # guidance 32 + blur 4 (+ sparse 4) + out 4
-        alg_bytes = px * bytes_per_px  # per launch (one forward = all n_iter iterations), per GPU
-        achieved = alg_bytes / (dev_ms_avg * 1e-3) / 1e9
+        B, H, W, n_iter, sparse, scale, desc, algo_name = (m[k] for k in ("B", "H", "W", "n_iter", "sparse", "scale", "desc", "algo_name"))
+        total_images, elapsed, dev_ms_avg = m["total_images"], m["elapsed"], m["dev_ms_avg"]
         res = {
             "metric": "CSPN iterations/sec (Mpix*iters/s), 3x3x24 at KITTI res" if a.workload.startswith("kitti")
                       else "CSPN iterations/sec (Mpix*iters/s)",
-            "value": round(value, 1),
+            "value": round(m["value"], 1),
             "unit": "Mpix*iters/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -397,36 +453,49 @@ def main():
             "dtype": "f32",
             "data": "synthetic (randn affinity, uniform depth*%g; image i of the global batch from torch.Generator().manual_seed(1000+i) "
                     "on the CPU, copied to HBM before the timed region)" % scale,
-            "prewarm_s": round(prewarm_s, 3), "prewarm_launches": prewarm_launches,
-            "parity_checked": parity,
+            "prewarm_s": round(m["prewarm_s"], 3), "prewarm_launches": m["prewarm_launches"],
+            "parity_checked": m["parity"],
             "config": {
                 "workload": ("%s, batch %d per GPU" % (desc, B)) if a.scaling == "weak"
                             else "%s, global batch %d sharded over %d GPU(s) (%d images on rank 0)" % (desc, total_images, world, B),
                 "B_per_gpu": B, "global_batch": total_images, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
-                "algo": algo_name, "guidance_layout": a.layout, "parallelism": "batch-sharded x%d, no data-path collective" % world
-                                          + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
+                "algo": algo_name, "guidance_layout": a.layout, **({"plan_mode": a.plan_mode} if a.plan_mode else {}),
+                "parallelism": "batch-sharded x%d, no data-path collective" % world
+                               + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("cspn2d_tsw3_kernel (gfx950 assembly main loop, LDS-DMA row slots; ONE launch per forward: every workgroup "
-                           "plans its own row stream in LDS, nothing else runs inside the timed region)"
-                           if not os.environ.get("CSPN_TSW_V2") else
-                           "cspn2d_tsw_kernel (round-2 assembly main loop, CSPN_TSW_V2=1)") if algo_name == "fused" and W >= 256 and n_iter == 24
+                "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
+                          "stream of its piece of the linear plan in LDS, nothing else runs inside the timed region)"
+                          if algo_name == "fused" and W >= 256 and W % 4 == 0 and n_iter == 24
                           else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
                           else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
-                "achieved": round(achieved, 1),
+                "achieved": round(m["achieved"], 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac": round(m["achieved"] / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_per_launch": m["alg_bytes"],
                 "device_ms_per_launch": round(dev_ms_avg, 4),
-                "device_ms_min": round(dev_ms[0], 4),
+                "device_ms_min": round(m["dev_ms_min"], 4),
             },
         }
-        if broadcast_ms is not None:
-            res["broadcast_ms"] = round(broadcast_ms, 3)
-            res["broadcast_bytes"] = BACKBONE_PARAMS * 4
+        if world > 1:
+            res["backend"] = backend
+            res["devices"] = {"visible": ndev, "name": torch.cuda.get_device_name(dev_index)}
+            res["broadcast_ms"] = round(broadcast_ms, 3) if broadcast_ms is not None else None
+            res["broadcast_bytes"] = BACKBONE_PARAMS * 4 if broadcast_ms is not None else 0
+            if broadcast_error is not None:
+                res["broadcast_error"] = broadcast_error
+        if strong is not None:
+            res["strong"] = {
+                "workload": "%s, global batch %d sharded over %d GPU(s) (%d images on rank 0)" % (desc, strong["total_images"], world, strong["B"]),
+                "value": round(strong["value"], 1), "unit": "Mpix*iters/s", "ms_per_step": round(strong["elapsed"] / a.steps * 1e3, 4),
+                "B_per_gpu": strong["B"], "global_batch": strong["total_images"],
+                "roofline_frac_per_gpu": round(strong["achieved"] / HBM_PEAK_GBS, 4), "device_ms_per_launch": round(strong["dev_ms_avg"], 4),
+                "parity_checked": strong["parity"]}
+        if notes:
+            res["notes"] = notes
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -441,8 +510,11 @@ def main():
             res["cpu_baseline"] = cpu_baseline(H, W, n_iter, sparse, scale, a.norm_type)
         print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        _barrier(dist, notes)
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

@@ -15,7 +15,10 @@ ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
 ABI_VERSION = 2
 
+HOOKS_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcspn_amd_hooks.so")
+
 _lib = None
+_hooks = None
 
 
 class CspnError(RuntimeError):
@@ -102,14 +105,39 @@ def load():
     lib.cspn3d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 7 + [vp, c_size_t, vp]
     lib.cspn3d_check_status.restype = c_int
     lib.cspn3d_check_status.argtypes = [vp]
-    lib.cspn_debug_tsw_loop.restype = None
-    lib.cspn_debug_tsw_loop.argtypes = [c_int]
-    lib.cspn_debug_3d_mute_tile.restype = None
-    lib.cspn_debug_3d_mute_tile.argtypes = [c_int]
-    lib.cspn_debug_3d_persistent_error.restype = c_int
-    lib.cspn_debug_3d_persistent_error.argtypes = [vp] + [c_int] * 4
     _lib = lib
     return lib
+
+
+def load_hooks():
+    """libcspn_amd_hooks.so: what tests and measuring tools need beyond the ABI (plan dumps, plan A/B, the muted-workgroup launch
+    of the persistent 3D kernel ...).  It links against libcspn_amd.so and calls the same code with the test's choice as an
+    argument; the product library itself exports no cspn_debug_* symbol and keeps no test state."""
+    global _hooks
+    if _hooks is not None:
+        return _hooks
+    load()   # the product library first (the hooks library resolves its symbols against it)
+    if not os.path.exists(HOOKS_PATH):
+        raise CspnError("cspn_amd: %s not found -- `make -C cspn_amd/csrc` builds it next to the product library" % HOOKS_PATH)
+    h = ctypes.CDLL(HOOKS_PATH)
+    c_int, vp = ctypes.c_int, ctypes.c_void_p
+    ip = ctypes.POINTER(c_int)
+    h.cspn_debug_tsw_plan_geo.restype = c_int
+    h.cspn_debug_tsw_plan_geo.argtypes = [c_int] * 5 + [ip]
+    h.cspn_debug_tsw_plan_cuts.restype = c_int
+    h.cspn_debug_tsw_plan_cuts.argtypes = [c_int] * 5 + [ip, ip, ip]
+    h.cspn_debug_tsw_dump_plan.restype = c_int
+    h.cspn_debug_tsw_dump_plan.argtypes = [c_int] * 5 + [vp, vp, vp]
+    h.cspn_debug_forward2d_plan.restype = c_int
+    h.cspn_debug_forward2d_plan.argtypes = [vp] * 4 + [c_int] * 6 + [vp, vp]
+    h.cspn_debug_3d_persistent_error.restype = c_int
+    h.cspn_debug_3d_persistent_error.argtypes = [vp] + [c_int] * 4
+    h.cspn_debug_3d_persistent_forward.restype = c_int
+    h.cspn_debug_3d_persistent_forward.argtypes = [vp] * 3 + [c_int] * 7 + [vp, vp]
+    h.cspn_debug_3d_backward_stepwise.restype = c_int
+    h.cspn_debug_3d_backward_stepwise.argtypes = [vp] * 5 + [c_int] * 5 + [vp, vp]
+    _hooks = h
+    return h
 
 
 def check(rc, what):

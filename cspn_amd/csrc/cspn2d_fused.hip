@@ -526,16 +526,6 @@ namespace cspn {
 namespace {
 #endif
 
-int num_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-        return v;
-    }();
-    return n;
-}
-
 int bands_of(int W, int halo) {
     if (W <= BW) return 1;
     int nb = 0, lo = 0;
@@ -572,7 +562,7 @@ size_t fused2d_workspace(int B, int H, int W, int n_iter) {
 }
 
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
-                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm) {
+                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm, int plan_mode) {
     if (((uintptr_t)out & 15u) != 0) { set_error("fused kernel needs a 16-byte aligned output"); return CSPN_E_UNSUPPORTED; }
     const int passes = (n_iter + LV - 1) / LV;
     float* pingpong = (float*)ws;
@@ -584,9 +574,13 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
         if (asm_ok && n == LV) {
-            if (tsw3_supported(B, H, W, sparse != nullptr, hin != blur)) {
+#ifdef CSPN_EXPERIMENTS
+            if (plan_mode == 3) {   // the round-3 loop (experiment builds only)
+                if (!tsw3_supported(B, H, W, sparse != nullptr, hin != blur)) { set_error("round-3 loop: unsupported call"); return CSPN_E_UNSUPPORTED; }
                 if (int e = tsw3_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
-            } else if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
+            } else
+#endif
+            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st, nullptr, plan_mode)) return e;
             hin = dst;
             done += n;
             continue;

@@ -9,8 +9,6 @@
 //   * injected with ten ds_read_b128,
 //   * row descriptors are 4 bytes: the table is 8 KB instead of 44 KB of LDS.
 // The C++ part only (1) builds the descriptor table in LDS, (2) hands kernel arguments to the asm block in fixed SGPRs.
-#include <atomic>
-#include <cstdlib>
 
 #include "cspn_common.h"
 #include "cspn2d_tsw_plan.h"
@@ -157,8 +155,6 @@ __global__ __launch_bounds__(NT, 2) void cspn2d_tsw3_kernel(const float* __restr
                                     __builtin_amdgcn_readfirstlane(4 * p0));
 }
 
-std::atomic<int> g_force_loop{0};
-
 PlanGeo make_geo3(int B, int H, int W) { return tswplan::make_geo(B, H, W, TSW3_PADF, TSW3_PADB, TSW3_TAB_MAX_ROWS); }
 
 template <int NORM>
@@ -182,17 +178,11 @@ bool tsw3_supported(int B, int H, int W, bool sparse, bool hin_differs) {
     if (!tsw2d_supported(B, H, W)) return false;
     if (sparse && hin_differs) return false;
     if (((long long)B << ybits_of(H)) >= (1ll << 28)) return false;   // image | row in 28 descriptor bits
-    static const int v2 = getenv("CSPN_TSW_V2") ? atoi(getenv("CSPN_TSW_V2")) : 0;   // A/B switches: always the round-2 loop /
-    static const int v3 = getenv("CSPN_TSW_V3") ? atoi(getenv("CSPN_TSW_V3")) : 0;   // always the round-3 loop
-    const int forced = g_force_loop.load(std::memory_order_relaxed);   // test hook (cspn_debug_tsw_loop)
-    if (forced == 2 || (!forced && v2)) return false;
-    if (forced == 3 || (!forced && v3)) return true;
-    // Measured on MI355X (profiles/r03_strong_scaling_shapes_1gpu.txt): with long row streams per workgroup the two loops tie
-    // (KITTI x 64: 463 rows per share, 0.287 vs 0.288 ms); with short ones the round-3 loop's longer prologue (LDS-DMA priming)
-    // and deeper pipeline cost 4 .. 8 % (KITTI x 8: 58 rows per share, 0.0706 vs 0.0660 ms).  Long streams take this loop.
-    const PlanGeo g = make_geo3(B, H, W);
-    const long long share = ((long long)B * H + g.ng - 1) / g.ng;
-    return share >= 256;
+    // Round 4: an experiment outside the default build (make EXPERIMENTS=1), reached only through the hook library's
+    // cspn_debug_forward2d_plan(..., plan_mode 3).  Measured on MI355X (profiles/r03_strong_scaling_shapes_1gpu.txt): with long row
+    // streams per workgroup it ties with the product loop (KITTI x 64: 0.287 vs 0.288 ms); with short ones its longer prologue
+    // (LDS-DMA priming) and deeper pipeline cost 4 .. 8 % (KITTI x 8: 0.0706 vs 0.0660 ms).
+    return true;
 }
 
 int tsw3_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H, int W,
@@ -206,9 +196,6 @@ int tsw3_pass(const float* gd, const float* blur, const float* hin, const float*
     }
     return check_launch("cspn2d_tsw3_kernel");
 }
-
-// test hook: which assembly loop takes the 24-iteration passes it supports -- 0: the rule above, 2: the round-2 loop, 3: the round-3 loop
-extern "C" void cspn_debug_tsw_loop(int which) { g_force_loop.store(which, std::memory_order_relaxed); }
 
 // test hooks: the planning arithmetic / the descriptor tables every workgroup would build for itself (tools/tswgen/plan3.py)
 extern "C" int cspn_debug_tsw3_plan_geo(int B, int H, int W, int* n_wg, int* stride) {

@@ -202,7 +202,7 @@ size_t backward3d_workspace(int B, int D, int H, int W, int n_iter) {
 int step3d_direct(const float* g, const float* hin, float* hout, int B, int D, int H, int W, hipStream_t st);   // cspn3d_stepwise.hip
 
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W,
-               int n_iter, void* ws, hipStream_t st) {
+               int n_iter, void* ws, hipStream_t st, bool stepwise_only) {
     const size_t total = (size_t)B * D * H * W;
     float* hist = (float*)ws;                                  // H_1 .. H_{n-1}
     float* ahist = hist + (size_t)(n_iter - 1) * total;        // A_1 .. A_{n-1}
@@ -214,7 +214,6 @@ int backward3d(const float* g, const float* feat, const float* gout, float* gg, 
     // level-keeping and transposed variants -- forward H_1 .. H_{n-1} (n - 1 steps, the last one "out" = H_{n-1}), adjoint
     // A_{n-1} .. A_0 (n steps).  One launch per step otherwise.
     void* pws = (char*)ws + levels_bytes(B, D, H, W, n_iter);
-    static const bool stepwise_only = getenv("CSPN_3D_BWD_STEPWISE") != nullptr;   // A/B switch
     const bool fused = vec && !stepwise_only && n_iter >= 3 && persistent3d_supported(B, D, H, W, n_iter - 1) &&
                        persistent3d_supported(B, D, H, W, n_iter);
     if (fused) {

@@ -17,7 +17,6 @@
 // Takes W % 4 == 0, W >= 64, 16-byte aligned tensors, 2 <= n_iter <= 60: the Paddle contract (norm NONE, no mask) directly, the
 // normalising / masked modes after fold3d_kernel (HASC), and the transposed operator of the backward (ADJ).  Everything else
 // runs cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
-#include <cstdlib>
 #include <mutex>
 
 #include "cspn_common.h"
@@ -55,7 +54,9 @@ struct Geo3 {
     int pitch, vw;           // columns between them are never inside a volume, so nothing flows across), vw = B pitch - 4
     int n_wg;                // workgroups launched (>= tz * ty * cx)
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
-    int mute;                // MUTE instantiation (test hook) only: the workgroup that never publishes
+    int mute;                // MUTE instantiation (test-hook library) only: the workgroup that never publishes
+    unsigned seq;            // number of this launch on its device (> 0): what a workgroup that gives up writes to *status
+    unsigned* status;        // the device's sticky status word (host-mapped, device-visible address)
     long long gps, gbs;      // gate plane / batch stride in floats: [B][26][V] as given (V, 26 V) or folded planes [26][B][V] (B V, V)
 };
 
@@ -91,9 +92,6 @@ __device__ __forceinline__ v4f ldq_sc1(const float4* base, unsigned byte_off) { 
 // the gate gradient multiplies with).
 // HASC: a constant term per voxel, H_{t+1} = c' + sum_k w'_k H_t(p + off_k): the folded form of the normalising / masked modes
 // (fold3d_kernel of cspn3d_stepwise.hip writes w' and c'); c' of the thread's eight voxels waits in LDS between the steps.
-// The sticky status word of this device (host-mapped; set once by the host, read by the kernel only when it gives up)
-__device__ unsigned* g_status3 = nullptr;
-
 // Gate quads of the NEXT chunk parked in the LDS the level buffers leave free (round 3): during the first NPRE / 2 steps of a
 // chunk each thread requests both quads of one gate plane of its voxels in the next chunk by LDS-DMA (global_load_lds_dwordx4:
 // no destination register -- the 208 gate registers leave none; M0 carries the LDS address, all 160 KB are reachable on gfx950,
@@ -541,8 +539,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                         if (lost) {
                             *err = 2;
-                            unsigned* st = g_status3;
-                            if (st) __hip_atomic_store(st, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (g.status) __hip_atomic_store(g.status, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             s_bail = 1;
                         }
                     }
@@ -562,11 +559,13 @@ struct Dev3 {
     int wgs = 0;                      // workgroups that can be resident at once: one per CU (the kernel takes a CU's whole
     hipEvent_t last = nullptr;        //   register file), at most MAX_WG
     hipStream_t last_stream = nullptr;
-    unsigned* status_host = nullptr;  // host-mapped; its device address is in the device's copy of g_status3
+    unsigned* status_host = nullptr;  // host-mapped; status_dev is its device address (a kernel argument: Geo3::status)
+    unsigned* status_dev = nullptr;
+    unsigned seq = 0;                 // launches so far; a workgroup that gives up stores its launch's number in the status word
+    unsigned reported = 0;            // the highest launch number persistent3d_take_status has reported
 };
 std::mutex g_mu3;
 Dev3 g_dev3[64];
-int g_mute3 = -1;   // test hook (one-shot): the workgroup of the next launch that never publishes
 
 Dev3& dev3() {
     int dev = 0;
@@ -629,7 +628,7 @@ size_t persistent3d_workspace(int B, int D, int H, int W) {
 // adjoint: the transposed operator (backward); levels: volume lv0 + it * lvs receives the result of step it < n_iter;
 // cprime != nullptr: gate holds the 26 folded planes [26][B][V] and cprime the constant term (normalising / masked modes)
 static int persistent3d_launch(const float* gate, const float* feat, const float* cprime, float* out, float* levels, int lv0, int lvs,
-                               bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st) {
+                               bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt) {
     Geo3 g = make_geo3(B, D, H, W, n_iter);
     g.lv0 = lv0;
     g.lvs = lvs;
@@ -648,26 +647,27 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     // apart with an event: a launch waits for the previous persistent launch (whatever stream it went to) and records itself.
     // Other work that happens to occupy CUs only delays the start; if it never lets go, the waiting workgroups give up after
     // SPIN_MAX polls (~0.5 s), take NaN for what did not come and raise the device's status word (persistent3d_take_status).
-    // CSPN_3D_COOP_LAUNCH=1 uses hipLaunchCooperativeKernel instead (the runtime then checks the residency too; ~23 us per
-    // launch, 0.905 -> 0.928 ms at config 5).  A stream that is being captured into a graph takes a plain launch: the replaying
-    // graph is the caller's to keep alone on the device.
+    // opt.coop (test-hook library only) uses hipLaunchCooperativeKernel instead (the runtime then checks the residency too; ~23 us
+    // per launch, 0.905 -> 0.928 ms at config 5).  A stream that is being captured into a graph takes a plain launch: the
+    // replaying graph is the caller's to keep alone on the device.
     std::lock_guard<std::mutex> lock(g_mu3);
     Dev3& d = dev3();
-    if (!d.status_host) {
-        unsigned* devp = nullptr;
+    if (!d.status_host) {   // first launch on this device: one pinned word; its device address travels as a kernel argument, so
+        // nothing here touches a stream (no symbol copy, no implicit synchronisation: safe under stream capture)
         e = hipHostMalloc((void**)&d.status_host, 64, hipHostMallocMapped);
-        if (e == hipSuccess) { *d.status_host = 0; e = hipHostGetDevicePointer((void**)&devp, d.status_host, 0); }
-        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_status3), &devp, sizeof(devp));
+        if (e == hipSuccess) { *d.status_host = 0; e = hipHostGetDevicePointer((void**)&d.status_dev, d.status_host, 0); }
         if (e != hipSuccess) { set_error("status word of the persistent kernel: %s", hipGetErrorString(e)); d.status_host = nullptr; return (int)e; }
     }
-    const int mute = g_mute3;
-    g_mute3 = -1;
+    const int mute = opt.mute;
     g.mute = mute;
+    if (++d.seq == 0) d.seq = 1;
+    g.seq = d.seq;
+    g.status = d.status_dev;
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
                    : adjoint ? (const void*)cspn3d_persistent_kernel<true, false>
                    : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
-    static const bool coop = getenv("CSPN_3D_COOP_LAUNCH") != nullptr;
+    const bool coop = opt.coop;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (coop && !capturing) {
@@ -692,24 +692,30 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     return check_launch("cspn3d_persistent_kernel");
 }
 
-// the sticky status of this device's persistent launches: 0 = none gave up since the last call of this function
-// (reads a pinned host word the kernel writes with a system-scope store: no synchronisation; clears it)
+// the sticky status of this device's persistent launches: 0 = no launch gave up that was not reported before.
+// Reads a pinned host word the kernel writes with a system-scope store (no synchronisation).  The word holds the NUMBER of the
+// launch that gave up: a launch is reported once -- its other workgroups run into their own timeouts later and store the same
+// number again, which a later, innocent call must not see as a second failure.  (Launches of a device are chained by an event, so
+// an older launch never overwrites a newer one's number.)
 int persistent3d_take_status() {
     std::lock_guard<std::mutex> lock(g_mu3);
     Dev3& d = dev3();
     if (!d.status_host) return 0;
-    return (int)__atomic_exchange_n(d.status_host, 0u, __ATOMIC_RELAXED);
+    const unsigned v = __atomic_load_n(d.status_host, __ATOMIC_RELAXED);
+    if (v == 0 || v == d.reported) return 0;
+    d.reported = v;
+    return 2;
 }
 
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
-                     int H, int W, int n_iter, void* ws, hipStream_t st) {
-    return persistent3d_launch(gate, feat, nullptr, out, levels, lv0, lvs, adjoint, B, D, H, W, n_iter, ws, st);
+                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt) {
+    return persistent3d_launch(gate, feat, nullptr, out, levels, lv0, lvs, adjoint, B, D, H, W, n_iter, ws, st, opt);
 }
 
 // H_{t+1} = c' + sum_k w'_k H_t(p + off_k) with the folded planes wf = [26 w'][c'] of fold3d_kernel
 int persistent3d_forward_folded(const float* wf, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                                 hipStream_t st) {
-    return persistent3d_launch(wf, feat, wf + 26 * (size_t)B * D * H * W, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st);
+    return persistent3d_launch(wf, feat, wf + 26 * (size_t)B * D * H * W, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st, P3Options());
 }
 
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
@@ -717,18 +723,12 @@ int persistent3d_forward(const float* gate, const float* feat, float* out, int B
     return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st);
 }
 
-// test hook: the error word of the last run in this workspace (0 ok, 1 barrier timeout, 2 neighbour-flag timeout); syncs
-extern "C" int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) {
+// (test-hook library) the error word of the last run in this workspace (0 ok, 2 neighbour-quad timeout); synchronises
+int persistent3d_error_word(const void* ws, int B, int D, int H, int W) {
     unsigned v = 0;
     const unsigned* p = (const unsigned*)((const char*)((const float*)ws + 2 * (size_t)B * D * H * W) + XBYTES) + MAX_WG + 64 * 9;
     if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)v;
-}
-
-// test hook: the workgroup of the NEXT plain (Paddle-contract) persistent launch that never publishes its boundary
-extern "C" void cspn_debug_3d_mute_tile(int wg) {
-    std::lock_guard<std::mutex> lock(g_mu3);
-    g_mute3 = wg;
 }
 
 }  // namespace cspn

@@ -2,6 +2,7 @@
 // Replaces the call boundary of Affinity_Propagate.forward
 // (reference cspn_pytorch/models/cspn.py:42-83) and of the chained
 // fluid.layers.affinity_propagate calls (reference cspn_paddle/demo.py:41-52).
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -25,6 +26,19 @@ int check_launch(const char* what) {
         return (int)e;
     }
     return 0;
+}
+
+int num_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) {
+        v = cache[dev].load(std::memory_order_relaxed);
+        if (v > 0) return v;
+    }
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 static int check_common(const void* a, const void* b, const void* out, int n_iter, int norm, const void* ws,
@@ -94,13 +108,25 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
 }
 
 // ---- SURVEY 8f-2 experiment: guidance as 32 contiguous bytes per pixel, pre-sited by the producer
+// Measured 9 % slower than the planar contract and closed: the loop variants are only in experiment builds
+// (make -C cspn_amd/csrc EXPERIMENTS=1); the default library answers "unsupported".
+#ifdef CSPN_EXPERIMENTS
 int cspn2d_sited8_supported(int B, int H, int W, int n_iter) { return n_iter == 24 && tsw2d_supported(B, H, W) ? 1 : 0; }   // (W >= 256, W % 4 == 0)
+#else
+int cspn2d_sited8_supported(int, int, int, int) { return 0; }
+#endif
 
 int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type, cspn_stream_t stream) {
     if (!guidance || !guidance_s8 || B <= 0 || H <= 0 || W <= 0 || (W % 2) != 0) { set_error("bad argument (W must be even)"); return CSPN_E_BADARG; }
     if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
     if (((uintptr_t)guidance_s8 & 15u) != 0) { set_error("guidance_s8 must be 16-byte aligned"); return CSPN_E_BADARG; }
+#ifdef CSPN_EXPERIMENTS
     return guidance_to_sited8(guidance, guidance_s8, B, H, W, norm_type, (hipStream_t)stream);
+#else
+    (void)stream;
+    set_error("the sited8 experiment is not part of this build (make EXPERIMENTS=1)");
+    return CSPN_E_UNSUPPORTED;
+#endif
 }
 
 int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const float* sparse, float* out, int B, int H, int W,
@@ -108,11 +134,16 @@ int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const
     if (!guidance_s8 || !blur || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
     if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
     if (!cspn2d_sited8_supported(B, H, W, n_iter)) {
-        set_error("the sited8 entry point takes passes of exactly 24 iterations on images >= 256 columns wide, W %% 4 == 0");
+        set_error("the sited8 entry point (experiment builds only) takes passes of exactly 24 iterations on images >= 256 columns wide, W %% 4 == 0");
         return CSPN_E_UNSUPPORTED;
     }
+#ifdef CSPN_EXPERIMENTS
     if ((((uintptr_t)guidance_s8 | (uintptr_t)out) & 15u) != 0) { set_error("guidance_s8 and out must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
     return tsw2d_pass_sited8(guidance_s8, blur, sparse, out, B, H, W, norm_type, (hipStream_t)stream);
+#else
+    (void)sparse; (void)stream;
+    return CSPN_E_UNSUPPORTED;
+#endif
 }
 
 size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter) {

@@ -24,6 +24,9 @@ __device__ __forceinline__ float signf(float s) { return s > 0.f ? 1.f : (s < 0.
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// CUs of the current device (queried once per device and kept: idempotent memoisation, no other state)
+int num_cus();
+
 // ---- stepwise path (one launch per iteration; general shapes) ----
 size_t stepwise2d_workspace(int B, int H, int W, int n_iter);
 int stepwise2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
@@ -41,9 +44,13 @@ int persistent3d_forward(const float* gate, const float* feat, float* out, int B
 // the folded form of the normalising / masked modes: wf = 26 planes w' + the constant term c' ([27][B*V], fold3d_kernel)
 int persistent3d_forward_folded(const float* wf, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                                 hipStream_t st);
+// launch options only the test-hook library sets (csrc/cspn_test_hooks.hip): mute = the workgroup that never publishes its
+// boundary (its neighbours then run into the poll timeout), coop = hipLaunchCooperativeKernel instead of the event chain
+struct P3Options { int mute = -1; bool coop = false; };
 // the same run for the backward: adjoint = transposed operator; levels + (lv0 + it * lvs) volumes receive step it < n_iter
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
-                     int H, int W, int n_iter, void* ws, hipStream_t st);
+                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt = P3Options());
+int persistent3d_error_word(const void* ws, int B, int D, int H, int W);
 
 // sticky per-device status of the persistent launches: != 0 once after a launch gave up (a workgroup waited in vain for a
 // neighbour: not all workgroups resident); read without synchronisation from a pinned host word, cleared by the read
@@ -52,22 +59,26 @@ int persistent3d_take_status();
 // ---- backward of the 3D op, Paddle contract only (cspn3d_backward.hip) ----
 size_t backward3d_workspace(int B, int D, int H, int W, int n_iter);
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W, int n_iter,
-               void* ws, hipStream_t st);
+               void* ws, hipStream_t st, bool stepwise_only = false /* test-hook library: one launch per step */);
 
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);
+// plan_mode (test-hook library only; the ABI passes 0): 0 the linear plan, 1 the same without XCD-aware placement, 2 band groups
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
-                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true);
+                    int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true, int plan_mode = 0);
 
 // ---- the same ring with the main loop in gfx950 assembly (cspn2d_tsw.hip); one pass = exactly 24 iterations ----
 bool tsw2d_supported(int B, int H, int W);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
-               int W, int norm, hipStream_t st, float* hist = nullptr);
-// ---- the round-3 loop (cspn2d_tsw3.hip): LDS-DMA row slots; forward passes without history ----
+               int W, int norm, hipStream_t st, float* hist = nullptr, int plan_mode = 0);
+#ifdef CSPN_EXPERIMENTS
+// ---- experiments kept out of the default build (make EXPERIMENTS=1): the round-3 loop (cspn2d_tsw3.hip: LDS-DMA row slots;
+// ties with the loop above on long streams, slower on short ones: profiles/r03_perf_notes.md) and the sited8 guidance layout ----
 bool tsw3_supported(int B, int H, int W, bool sparse, bool hin_differs);
 int tsw3_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H, int W,
               int norm, hipStream_t st);
+#endif
 int guidance_to_sited8(const float* g, float* out, int B, int H, int W, int norm, hipStream_t st);
 int tsw2d_pass_sited8(const float* g8, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm,
                       hipStream_t st);

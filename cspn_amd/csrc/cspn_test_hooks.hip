@@ -1,0 +1,89 @@
+// cspn_test_hooks.hip -> libcspn_amd_hooks.so: everything the tests and the measuring tools need that is NOT part of the
+// product's ABI.  The product library (libcspn_amd.so) exports no cspn_debug_* symbol, reads no environment variable and keeps no
+// test state; this library links against it and reaches the same code through internal entry points that take the test's choice
+// as an ARGUMENT (plan mode, muted workgroup, launch kind, one launch per step), so one copy of the product code runs in the
+// process and nothing global is switched.  Built by the same Makefile; loaded by cspn_amd._lib.load_hooks().
+#include "cspn_common.h"
+#include "cspn2d_tsw_desc.h"
+#include "cspn2d_tsw_gen.inc"   // only the TSW_PADF / TSW_PADB / TSW_TAB_MAX_ROWS constants are used here
+
+using namespace cspn;
+using namespace cspn::tswplan;
+
+namespace {
+
+// the same descriptor functions every workgroup of cspn2d_tsw_kernel runs, one thread per (workgroup, table entry), into global memory
+__global__ void cspn2d_plan_dump_kernel(int4* __restrict__ hdr, uint4* __restrict__ tab, PlanGeo g) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= g.n_wg * g.stride) return;
+    const int wg = gid / g.stride, e = gid - wg * g.stride;
+    int Q = 0;
+    tab[(size_t)wg * g.stride + e] = tsw_desc(g, wg, e - TSW_PADF, &Q);
+    if (e == 0) hdr[wg] = tsw_header(g, wg, Q);
+}
+
+PlanGeo geo_of(int B, int H, int W, int plan_mode, int hist) {
+    if (hist) return make_geo(B, H, W, TSW_PADF, TSW_PADB, TSW_TAB_MAX_ROWS, 0, plan_mode != 1);
+    return make_geo_linear(B, H, W, TSW_PADF, TSW_PADB, TSW_TAB_MAX_ROWS, plan_mode);
+}
+
+}  // namespace
+
+extern "C" {
+
+// the plan a 24-iteration pass of this shape gets (hist != 0: the history / adjoint variants' band groups).
+// info[8] = kind, n_wg, stride, kimg, xcd, per_xcd, ng, nb
+int cspn_debug_tsw_plan_geo(int B, int H, int W, int plan_mode, int hist, int* info) {
+    const PlanGeo g = geo_of(B, H, W, plan_mode, hist);
+    const int v[8] = {g.kind, g.n_wg, g.stride, g.kimg, g.xcd, g.kind ? g.per_xcd : (g.gpx | (g.extra << 8) | (g.per_xcd << 16)), g.ng, g.nb};
+    for (int i = 0; i < 8; ++i) info[i] = v[i];
+    return 0;
+}
+
+// the linear plan's cuts, computed for a given CU count WITHOUT a device (CPU tests hold the C++ optimiser to tools/tswgen/plan.py).
+// cut: n_wg + 1 ints; -> n_wg (0: the linear plan does not apply), *kimg, *stride
+int cspn_debug_tsw_plan_cuts(int B, int H, int W, int ncu, int xcd, int* cut, int* kimg, int* stride) {
+    PlanGeo g;
+    if (!make_geo_linear_uncached(g, B, H, W, TSW_PADF, TSW_PADB, TSW_TAB_MAX_ROWS, ncu, xcd != 0)) return 0;
+    for (int i = 0; i <= g.n_wg; ++i) cut[i] = g.cut[i];
+    *kimg = g.kimg;
+    *stride = g.stride;
+    return g.n_wg;
+}
+
+// the descriptor tables every workgroup would build for itself (hdr: n_wg x int4, tab: n_wg x stride x uint4, device pointers)
+int cspn_debug_tsw_dump_plan(int B, int H, int W, int plan_mode, int hist, void* hdr, void* tab, void* stream) {
+    const PlanGeo g = geo_of(B, H, W, plan_mode, hist);
+    const int n = g.n_wg * g.stride;
+    hipLaunchKernelGGL(cspn2d_plan_dump_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int4*)hdr, (uint4*)tab, g);
+    return check_launch("cspn2d_plan_dump_kernel");
+}
+
+// cspn2d_forward_f32 (fused algo) with the plan chosen by the caller: 0 the product's, 1 without XCD-aware placement, 2 band groups
+// (the round-1..3 plan), 3 (experiment builds) the round-3 loop
+int cspn_debug_forward2d_plan(const float* guidance, const float* blur, const float* sparse, float* out, int B, int H, int W, int n_iter,
+                              int norm_type, int plan_mode, void* ws, void* stream) {
+    if (!fused2d_supported(B, H, W, n_iter)) return CSPN_E_UNSUPPORTED;
+    return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream, true, plan_mode);
+}
+
+// error word of the last persistent 3D run in this workspace (0 ok, 2 neighbour-quad timeout); synchronises
+int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) { return persistent3d_error_word(ws, B, D, H, W); }
+
+// the Paddle-contract persistent launch with workgroup `mute` never publishing its boundary (-1: nobody), coop != 0: cooperative launch
+int cspn_debug_3d_persistent_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, int mute,
+                                     int coop, void* ws, void* stream) {
+    if (!persistent3d_supported(B, D, H, W, n_iter)) return CSPN_E_UNSUPPORTED;
+    P3Options opt;
+    opt.mute = mute;
+    opt.coop = coop != 0;
+    return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, (hipStream_t)stream, opt);
+}
+
+// cspn3d_backward_f32 with one launch per step (A/B against the fused sweeps)
+int cspn_debug_3d_backward_stepwise(const float* gate, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W,
+                                    int n_iter, void* ws, void* stream) {
+    return backward3d(gate, feat, gout, gg, gf, B, D, H, W, n_iter, ws, (hipStream_t)stream, true);
+}
+
+}  // extern "C"

@@ -13,9 +13,18 @@
  *     the current HIP device; the call only ENQUEUES work on `stream` and returns
  *     (no hipDeviceSynchronize, no device allocation; safe to call from several
  *     host threads, cf. nn.DataParallel at reference cspn_pytorch/eval.py:117).
- *     The only state the library keeps between calls belongs to the persistent 3D
- *     kernel: per device, the event that chains its launches and one pinned status
- *     word (see cspn3d_check_status); everything else lives in the arguments;
+ *     State the library keeps between calls -- the complete list:
+ *       (1) the persistent 3D kernel's, per device: the event that chains its
+ *           launches, one pinned status word and two launch counters (see
+ *           cspn3d_check_status);
+ *       (2) memoisation with no effect on results: the CU count per device, and
+ *           per host thread the last four 2D forward plans (cut positions of the
+ *           linear plan, ~1 ms of host arithmetic per new shape).
+ *     Nothing else: the library reads no environment variable and exports no test
+ *     switch.  What tests and measuring tools need beyond this header (plan dumps,
+ *     plan A/B, a persistent launch with a muted workgroup) is a SEPARATE library,
+ *     libcspn_amd_hooks.so (csrc/cspn_test_hooks.hip), which links against this
+ *     one and passes the test's choice as an argument of internal entry points;
  *   - inputs are never written; `out` must not alias an input;
  *   - return 0 on success, a negative CSPN_E_* code on argument errors, or a
  *     positive hipError_t; cspn_last_error() gives a thread-local message;
@@ -83,7 +92,9 @@ int cspn2d_auto_algo(int B, int H, int W, int n_iter);
  * cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206,372); norm NONE: the centre-sited g_k(p).
  * cspn2d_guidance_to_sited8_f32 is that epilogue as a stand-alone kernel (tests, A/B timing).  Only where
  * cspn2d_sited8_supported(...) != 0 (passes of exactly 24 iterations, W >= 256, W % 4 == 0); no workspace.
- * (SURVEY 8f-2 was measured with this entry point and closed: 9 % slower than the planar contract) */
+ * (SURVEY 8f-2 was measured with this entry point and closed: 9 % slower than the planar contract, DESIGN.md 3.6.  Round 4:
+ * its loop variants are only in experiment builds -- make -C cspn_amd/csrc EXPERIMENTS=1 --; in the default library
+ * cspn2d_sited8_supported() is 0 for every shape and the other two entry points return CSPN_E_UNSUPPORTED.) */
 int cspn2d_sited8_supported(int B, int H, int W, int n_iter);
 int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type,
                                   cspn_stream_t stream);

@@ -94,7 +94,7 @@ def test_bench_two_ranks_launch_path():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--batch-per-gpu", "4", "--prewarm-s", "0.1", "--no-cpu-baseline"]
+           "--batch-per-gpu", "4", "--global-batch", "6", "--prewarm-s", "0.1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -103,6 +103,16 @@ def test_bench_two_ranks_launch_path():
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
     assert res["parity_checked"]["ok"] and res["parity_checked"]["all_ranks_ok"]
     assert res["value"] > 0 and res["roofline"]["frac"] > 0
+    # round 4: what the driver's N > 1 run must show even if a collective misbehaves -- who ran where, the broadcast's fate, and
+    # BASELINE config 3 as written (the strong shape) beside the weak-scaling headline
+    for rank in (0, 1):
+        assert "[bench.py rank %d/2] device 0 of 1" % rank in r.stderr, r.stderr[-2000:]
+    assert res["backend"] == "gloo" and res["devices"]["visible"] == 1
+    assert "broadcast_ms" in res and res["broadcast_ms"] is None and res["broadcast_bytes"] == 0 and "broadcast_error" not in res
+    st = res["strong"]
+    assert st["global_batch"] == 6 and st["B_per_gpu"] == 3 and st["value"] > 0 and 0 < st["roofline_frac_per_gpu"] < 1
+    assert st["parity_checked"]["ok"] and st["parity_checked"]["all_ranks_ok"]
+    assert "notes" not in res, res.get("notes")
 
 
 def test_bench_two_ranks_strong_scaling_shards_the_global_batch():

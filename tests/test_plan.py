@@ -9,7 +9,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.tswgen import kernel as K  # noqa: E402
-from tools.tswgen.plan import build_plan, plan_bands, plan_geo  # noqa: E402
+from tools.tswgen.plan import LinearPlan, build_plan, build_plan_linear, plan_bands, plan_geo  # noqa: E402
 
 CASES = [
     # B, H, W, max_wg (CUs), xcd placement?
@@ -61,3 +61,74 @@ def test_every_pixel_owned_exactly_once(B, H, W, max_wg, xcd):
             if flags >> K.F_OWNED & 1:
                 owned[b, y, p0 + lo:p0 + hi] += 1
     assert owned.min() == 1 and owned.max() == 1
+
+
+LINEAR_CASES = [
+    # B, H, W, CUs
+    (64, 304, 1216, 256), (32, 304, 1216, 256), (8, 304, 1216, 256), (16, 228, 304, 256), (3, 33, 304, 256), (1, 150, 516, 4),
+    (2, 60, 304, 3), (5, 77, 772, 64), (1, 7, 256, 256), (7, 304, 1216, 304),
+]
+
+
+@pytest.mark.parametrize("B,H,W,ncu", LINEAR_CASES)
+def test_linear_plan_every_pixel_owned_exactly_once(B, H, W, ncu):
+    """round 4, the forward passes' plan: one contiguous piece of the (chunk, band, row) order per CU"""
+    n_iter = 24
+    lp, hdr, tab = build_plan_linear(B, H, W, n_iter, ncu)
+    assert lp.cut[0] == 0 and lp.cut[-1] == lp.total and all(a <= b for a, b in zip(lp.cut, lp.cut[1:]))
+    assert max(lp.stream_len(a, b) for a, b in zip(lp.cut, lp.cut[1:])) == lp.L == tab.shape[1] - K.PADF - K.PADB
+    owned = np.zeros((B, H, W), np.int32)
+    for g in range(lp.n_wg):
+        Q = int(hdr[g, 0])
+        assert int(hdr[g, 2]) == -1
+        assert not tab[g, :K.PADF].any() and not tab[g, K.PADF + Q:].any()
+        for d in tab[g, K.PADF:K.PADF + Q]:
+            flags = int(d[3])
+            if not flags & 1:
+                assert not d.any()
+                continue
+            e = int(d[2]) // 4
+            b, rem = divmod(e, H * W)
+            y, p0 = divmod(rem, W)
+            lo, hi = (flags >> 8) & 0xfff, (flags >> 20) & 0xfff
+            assert (p0, p0 + lo, p0 + hi) in lp.bands and p0 + 256 <= W
+            assert bool(flags >> K.F_FIRST & 1) == (p0 == 0) and bool(flags >> K.F_LAST & 1) == (p0 + 256 == W)
+            if flags >> K.F_OWNED & 1:
+                owned[b, y, p0 + lo:p0 + hi] += 1
+    assert owned.min() == 1 and owned.max() == 1
+
+
+def test_linear_plan_of_the_benchmarked_shape():
+    """BASELINE config 3 at 64 images on 256 CUs: 256 pieces of exactly 1.5 (image, band) units, one mid-image cut each = 481 stream
+    rows (513 with 42 band groups on 252 CUs); chunks of 3 images, so the pieces of neighbouring bands cover the same rows"""
+    lp = LinearPlan(64, 304, 1216, 24, 256)
+    assert (lp.kimg, lp.L, lp.n_wg, lp.per_xcd) == (3, 481, 256, 32)
+    assert lp.cut == [456 * i for i in range(257)]
+    lens = [lp.stream_len(a, b) for a, b in zip(lp.cut, lp.cut[1:])]
+    assert min(lens) == max(lens) == 481
+    for p in (0, 1, 2, 3, 13):   # pieces 2 b, 2 b + 1 of a chunk = band b; band b + 1 covers the same rows two pieces later
+        ra, rb = lp.runs(lp.cut[p], lp.cut[p + 1]), lp.runs(lp.cut[p + 2], lp.cut[p + 3])
+        if len(ra) == 1 and len(rb) == 1 and rb[0][0] == ra[0][0] + 1:
+            assert ra[0][1:] == rb[0][1:]
+    last = [lp.runs(lp.cut[p], lp.cut[p + 1]) for p in range(252, 256)]   # the 64th image: 6 band units over 4 CUs
+    assert [len(r) for r in last] == [2, 2, 2, 2] and last[0][0] == (0, 63 * 304, 64 * 304)
+    legacy_share = -(-64 * 304 // 42)
+    assert legacy_share + 48 + 1 >= 513 > lp.L
+
+
+@pytest.mark.parametrize("B,H,W,ncu", LINEAR_CASES + [(12000, 64, 256, 256)])
+def test_cxx_planner_matches_the_numpy_twin(B, H, W, ncu):
+    """the optimiser as the library runs it on the host (csrc/cspn2d_tsw_plan.h make_geo_linear, reached through the hook library;
+    no GPU involved) against tools/tswgen/plan.py"""
+    import ctypes
+    from cspn_amd import _lib
+    hooks = _lib.load_hooks()
+    cut = (ctypes.c_int * 258)()
+    kimg, stride = ctypes.c_int(), ctypes.c_int()
+    n = hooks.cspn_debug_tsw_plan_cuts(B, H, W, ncu, 1, cut, ctypes.byref(kimg), ctypes.byref(stride))
+    if B * H * len(plan_bands(W, 24)) // min(ncu, 256) > K.TAB_MAX_ROWS - K.PADF - K.PADB:
+        assert n == 0   # too long for a table: the library falls back to band groups
+        return
+    lp = LinearPlan(B, H, W, 24, ncu)
+    assert n == lp.n_wg and kimg.value == lp.kimg and stride.value == lp.stride
+    assert list(cut[:n + 1]) == lp.cut

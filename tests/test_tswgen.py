@@ -32,6 +32,19 @@ def test_emulated_asm_loop_vs_oracle(B, H, W, n_wg, norm, sparse, hin, zp):
         assert np.isnan(ref).any()
 
 
+@pytest.mark.parametrize("B,H,W,ncu,norm,sparse", [(2, 21, 304, 3, 0, True), (1, 150, 516, 4, 1, False), (2, 60, 304, 3, 2, True)])
+def test_emulated_asm_loop_on_linear_plan_pieces_that_change_band(B, H, W, ncu, norm, sparse):
+    """round 4: the forward passes' linear plan -- a workgroup's piece may end one band's rows and continue with the next band's
+    (the retirement re-derives the owned-lane mask from the row's descriptor): every pixel still comes out right"""
+    from tools.tswgen.plan import LinearPlan
+    lp = LinearPlan(B, H, W, 24, ncu, xcd=False)
+    assert any(len({r[0] for r in lp.runs(lp.cut[p], lp.cut[p + 1])}) > 1 for p in range(lp.n_wg)), "no piece changes band: pick another case"
+    os.chdir(ROOT)
+    err, nanmis, out, ref = run_case(B, H, W, 0, norm, sparse, False, seed=ncu, zero_patch=(norm != 2), verbose=False, linear=ncu)
+    assert nanmis == 0
+    assert err <= 1e-4, err
+
+
 @pytest.mark.parametrize("norm,sparse", [(0, True), (1, False), (2, True)])
 def test_emulated_sited8_input_variant(norm, sparse):
     """cfg s8 (SURVEY 8f-2 experiment): the guidance arrives pre-sited and pair-interleaved, four aligned 16-byte loads per task"""

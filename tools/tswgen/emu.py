@@ -414,6 +414,8 @@ class Emu(object):
             self.ws(w, d[0], rs(w, s[0]) if w.scc else rs(w, s[1]))
         elif o == "s_cselect_b64":
             self.ws64(w, d[0], self.rs64(w, s[0]) if w.scc else self.rs64(w, s[1]))
+        elif o == "s_bfm_b64":
+            self.ws64(w, d[0], (((1 << (rs(w, s[0]) & 63)) - 1) << (rs(w, s[1]) & 63)) & 0xffffffffffffffff)
         else:
             raise EmuError("unknown SALU op " + o)
 

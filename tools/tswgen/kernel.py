@@ -88,6 +88,7 @@ V_PF, V_PFD = V(74), V(75)   # cfg pf (not with hist: V_DN): per-lane byte offse
 S_PFB = S(54, 2)             # cfg pf: base address of the row being prefetched
 S_LOHI = S(13)   # input: owned columns of this workgroup's band, band relative: lo | hi << 16 (one band per workgroup)
 S_OMASK = S(42, 2)  # lanes whose 4 columns lie inside [lo, hi)
+S_LOHIC = S(0)      # cfg mband (forward variants; s0 is S_HM[0] in history mode): lo | hi << 12 of the row S_OMASK was derived from
 S_TAU, S_ACT, S_QB, S_PQ, S_PFLAGS = S(45), S(33), S(34), S(35), S(36)  # (s32 is reserved by the compiler: stack pointer)
 S_AM = [S(56), S(57), S(58), S(59)]   # per ring slot: -1 if it holds a real row, 0 for a separator / padding row (round 3)
 S_EL, S_ER = S(38, 2), S(40, 2)
@@ -140,6 +141,14 @@ class Gen(object):
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
         self.estubs = []
+        # mband (round 4): a workgroup's stream may continue in the next band (linear plan, cspn2d_tsw_plan.h kind 1).  Everything
+        # about a row's band travels in its descriptor already (offsets, first / last band, lo | hi); only the mask of the lanes
+        # that own columns was a per-workgroup constant: a retirement now compares the row's lo | hi with the pair the mask was
+        # derived from (2 scalar instructions + a never-taken branch) and re-derives it out of line when the band changed.
+        # The history / adjoint / sited8 variants keep one band per workgroup (their per-slot masks are taken at injection).
+        self.mband = cfg.get("mband", not (self.hist or self.adj or self.s8))
+        assert not (self.mband and self.hist)
+        self.mstubs = []
         self.elastic = cfg.get("elastic", False)
         if self.elastic:
             assert not (self.hist or self.hin or cfg.get("pf") or cfg.get("trace") or cfg.get("cook_early") or cfg.get("spread3"))
@@ -265,13 +274,20 @@ class Gen(object):
         self.e("s_cbranch_scc0", (), [lab])
         self.e("s_bitcmp1_b32", (), [eo[1], F_OWNED])
         self.e("s_cbranch_scc0", (), [lab])
+        if self.mband:
+            stub, back = self.p.newlabel("mband"), self.p.newlabel("mbback")
+            self.e("s_lshr_b32", T[10], [eo[1], 8])           # lo | hi << 12 of the retiring row's band
+            self.e("s_cmp_lg_u32", (), [T[10], S_LOHIC])
+            self.e("s_cbranch_scc1", (), [stub])
+            self.p.label(back)
+            self.mstubs.append((stub, back))
         self.mov(OUTQ[0], vq[0])   # registers hold (c0,c3,c1,c2)
         self.mov(OUTQ[1], vq[2])
         self.mov(OUTQ[2], vq[3])
         self.mov(OUTQ[3], vq[1])
         self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
         self.e("s_addc_u32", T[9], [S_OUT[1], 0])
-        self.e("s_mov_b64", EXEC, [S_OMASK])   # the owned columns are the same for every row of this workgroup's band
+        self.e("s_mov_b64", EXEC, [S_OMASK])   # the owned columns of the row's band (mband: kept current by the check above)
         if "nostore" not in self.ab:
             self.e("global_store_dwordx4", (), [V_L16, OUTQ, S(T[8].i, 2)], cache=self.cfg.get("st_cache"))
         self.e("s_mov_b64", EXEC, [-1])
@@ -880,11 +896,15 @@ class Gen(object):
         for j in range(4):
             e("s_mov_b32", S_AM[j], [0])
         e("s_mov_b64", VCC, [1])
-        e("s_and_b32", T[2], [S_LOHI, 0xffff])
-        e("s_lshr_b32", T[3], [S_LOHI, 16])
-        e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
-        e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
-        e("s_and_b64", S_OMASK, [S(T[4].i, 2), S(T[6].i, 2)])
+        if self.mband:   # the first retirement derives the mask (no descriptor has lo | hi << 12 == -1)
+            e("s_mov_b32", S_LOHIC, [-1])
+            e("s_mov_b64", S_OMASK, [0])
+        else:
+            e("s_and_b32", T[2], [S_LOHI, 0xffff])
+            e("s_lshr_b32", T[3], [S_LOHI, 16])
+            e("v_cmp_ge_u32", S(T[4].i, 2), [V_COL4, T[2]])
+            e("v_cmp_lt_u32", S(T[6].i, 2), [V_COL4, T[3]])
+            e("s_and_b64", S_OMASK, [S(T[4].i, 2), S(T[6].i, 2)])
         if self.hist:
             for j in range(4):
                 e("s_mov_b64", S_HM[j], [0])
@@ -1144,6 +1164,18 @@ class Gen(object):
             self.e("s_bitcmp1_b32", (), [S_ACT, j])
             self.e("s_cbranch_scc1", (), [back])
             self.zero_quad(vq)
+            self.e("s_branch", (), [back])
+        for stub, back in self.mstubs:
+            # the band changed: S_OMASK <- lanes [lo / 4, hi / 4) of the new band (T[10] = lo | hi << 12, from retire())
+            self.p.label(stub)
+            self.e("s_mov_b32", S_LOHIC, [T[10]])
+            self.e("s_and_b32", T[11], [T[10], 0xfff])
+            self.e("s_lshr_b32", T[11], [T[11], 2])
+            self.e("s_lshr_b32", T[10], [T[10], 14])
+            self.e("s_sub_u32", T[10], [T[10], T[11]])
+            self.e("s_bfm_b64", S_OMASK, [T[10], T[11]])      # ((1 << width) - 1) << first; width 64 wraps to 0:
+            self.e("s_cmp_eq_u32", (), [T[10], 64])
+            self.e("s_cselect_b64", S_OMASK, [-1, S_OMASK])
             self.e("s_branch", (), [back])
         self.p.label(".Lend_%=")
         return self.p

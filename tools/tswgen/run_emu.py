@@ -11,7 +11,9 @@ from .plan import build_plan
 
 
 def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False, hist_every=1,
-             s8=False, elastic=False, sched_seed=None):
+             s8=False, elastic=False, sched_seed=None, linear=None):
+    """linear = number of CUs: the forward passes' linear plan (tools/tswgen/plan.py LinearPlan: one contiguous piece of the
+    band-row order per CU; a piece may continue in the next band) instead of band groups"""
     sys.path.insert(0, ".")
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
@@ -36,8 +38,13 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
     nb = len(plan_bands(W, n_iter))
-    n_wg = -(-n_wg // nb) * nb   # whole groups of nb workgroups
-    hdr, tab = build_plan(B, H, W, n_iter, n_wg)
+    if linear:
+        from .plan import build_plan_linear
+        lp, hdr, tab = build_plan_linear(B, H, W, n_iter, linear, xcd=False)
+        n_wg = lp.n_wg
+    else:
+        n_wg = -(-n_wg // nb) * nb   # whole groups of nb workgroups
+        hdr, tab = build_plan(B, H, W, n_iter, n_wg)
     # global memory image
     def al(n):
         return (n + 4095) // 4096 * 4096
@@ -77,7 +84,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             set64(K.S_OUT, off["out"])
             set64(K.S_PLAN, off["plan"] + wg * tab.shape[1] * 16)
             w.s[K.S_NROWS.i] = max(0, g.nbytes - 7 * 4 * H * W - 2 * 4 * W)   # S_GLAST (cfg pf); S_NROWS when tab_in_lds = False
-            w.s[K.S_LOHI.i] = int(hdr[wg, 2])
+            w.s[K.S_LOHI.i] = int(hdr[wg, 2]) & 0xffffffff
             if hist:
                 set64(K.S_HIST, off["hist"])
                 set64(K.S_HSTRIDE, blur.nbytes)
