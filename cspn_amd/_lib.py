@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
 ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 HOOKS_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcspn_amd_hooks.so")
 
@@ -103,6 +103,10 @@ def load():
     lib.cspn3d_workspace_bytes_ex.argtypes = [c_int] * 7
     lib.cspn3d_forward_f32_algo.restype = c_int
     lib.cspn3d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 7 + [vp, c_size_t, vp]
+    lib.cspn3d_multi_supported.restype = c_int
+    lib.cspn3d_multi_supported.argtypes = [c_int] * 6
+    lib.cspn3d_forward_multi_f32.restype = c_int
+    lib.cspn3d_forward_multi_f32.argtypes = [vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
     lib.cspn3d_check_status.restype = c_int
     lib.cspn3d_check_status.argtypes = [vp]
     _lib = lib

@@ -17,6 +17,7 @@
 // Takes W % 4 == 0, W >= 64, 16-byte aligned tensors, 2 <= n_iter <= 60: the Paddle contract (norm NONE, no mask) directly, the
 // normalising / masked modes after fold3d_kernel (HASC), and the transposed operator of the backward (ADJ).  Everything else
 // runs cspn3d_stepwise.hip.  Parity unpinned (the Paddle op's source is not in the reference tree), checked against oracle/.
+#include <cstddef>
 #include <mutex>
 
 #include "cspn_common.h"
@@ -55,10 +56,14 @@ struct Geo3 {
     int n_wg;                // workgroups launched (>= tz * ty * cx)
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
     int mute;                // MUTE instantiation (test-hook library) only: the workgroup that never publishes
+    int C;                   // MULTI instantiation only: value channels that share the gates (feat / out are [B][C][V])
     unsigned seq;            // number of this launch on its device (> 0): what a workgroup that gives up writes to *status
     unsigned* status;        // the device's sticky status word (host-mapped, device-visible address)
     long long gps, gbs;      // gate plane / batch stride in floats: [B][26][V] as given (V, 26 V) or folded planes [26][B][V] (B V, V)
 };
+
+constexpr int GEO3_KERNARG_OFFSET = 7 * 8;   // cspn3d_persistent_kernel(7 pointers, Geo3): where g starts in the kernel-argument segment
+static_assert(alignof(Geo3) == 8 && offsetof(Geo3, status) % 8 == 0, "Geo3 layout (the timeout path reads seq / status by offset)");
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -108,7 +113,10 @@ __device__ __forceinline__ void lds_dma16(unsigned byte_off, const float* base, 
 }
 
 // MUTE (test hook): workgroup g.mute computes but never publishes, so that its neighbours run into the poll timeout
-template <bool ADJ, bool HASC, bool MUTE = false>
+// MULTI (round 4): feat / out hold C value channels per volume that share the gates (reference cspn_paddle/README.md:56: "gate_weight
+// would be shared in the channel dimension for input when C>1"): the gates of a chunk are loaded ONCE and stay in the registers
+// while the n_iter steps are run for one channel after the other (only level 0 is re-read per channel, 4 B/voxel against 104)
+template <bool ADJ, bool HASC, bool MUTE = false, bool MULTI = false>
 __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) void cspn3d_persistent_kernel(const float* __restrict__ gate, const float* __restrict__ feat,
                                                                  const float* __restrict__ cprime, float* __restrict__ out,
                                                                  float* __restrict__ levels, float* __restrict__ scratch,
@@ -129,6 +137,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     const int tid = threadIdx.x, wg = blockIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
+    const int nch = MULTI ? g.C : 1;
+    const int FBS = MULTI ? g.C * (int)V : (int)V;   // volume stride of the value tensors in floats ([B][C][V])
     float4* X = reinterpret_cast<float4*>(scratch + 2 * total);   // [2][n_wg][NQ] published boundaries
     const int tiles = g.tz * g.ty * g.cx;
     const bool have_tile = wg < tiles;
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool in0 = in_zy && xq0 >= 0 && xq0 + 3 < g.W && b0 < g.B, in1 = in_zy && xq1 >= 0 && xq1 + 3 < g.W && b1 < g.B;
                 const int row = (z * g.H + y) * g.W;
                 // byte offsets: 1-channel tensors (feat, c') and the gate tensor (volume stride gbs floats)
-                const unsigned fo0 = in0 ? (unsigned)(b0 * (int)V + row + xq0) * 4u : 0u, fo1 = in1 ? (unsigned)(b1 * (int)V + row + xq1) * 4u : 0u;
+                const unsigned fo0 = in0 ? (unsigned)(b0 * FBS + row + xq0) * 4u : 0u, fo1 = in1 ? (unsigned)(b1 * FBS + row + xq1) * 4u : 0u;
                 const unsigned go0 = (unsigned)(b0 * (int)g.gbs + row + xq0) * 4u, go1 = (unsigned)(b1 * (int)g.gbs + row + xq1) * 4u;
                 const unsigned voff0 = in0 ? go0 : 0u, voff1 = in1 ? go1 : 0u;
                 auto shell_pos = [&](int i, int& pz, int& py, int& px) {
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     int vb, vx;
                     loc(x0 + px - 1, vb, vx);
                     const bool ok = i < NSH && vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W && vb < g.B;
-                    const unsigned so = ok ? (unsigned)(vb * (int)V + (vz * g.H + vy) * g.W + vx) * 4u : 0u;
+                    const unsigned so = ok ? (unsigned)(vb * FBS + (vz * g.H + vy) * g.W + vx) * 4u : 0u;
                     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(fs[j]) : "v"(so), "s"(fb) : "memory");
                 }
                 v4f cq0, cq1;
@@ -244,15 +254,22 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 // ---- the 26 gates of the thread's eight voxels: read once, kept in registers for all steps
                 v4f w[26][2];
+                // the 26 plane bases are worked out per chunk from an opaque copy of the plane stride: computed once per kernel they
+                // were 52 scalar registers live across everything (all of them spilled to VGPR lanes, which cost the vector
+                // registers the gates need: round 3 had 50 .. 78 SGPR spills and a VGPR spill per variant)
+                long long gps_c = g.gps;
+                asm volatile("" : "+s"(gps_c));
+                int Hc = g.H, Wc = g.W;   // (ADJ: the 26 row shifts, the same way)
+                if (ADJ) asm volatile("" : "+s"(Hc), "+s"(Wc));
 #pragma unroll
                 for (int k = 0; k < 26; ++k) {
-                    const float* gk = gate + (size_t)k * g.gps;
+                    const float* gk = gate + (size_t)k * (size_t)gps_c;
                     if (ADJ) {
                         const int c27 = k < 13 ? k : k + 1, dz = 1 - c27 / 9, dy = 1 - (c27 / 3) % 3, dx = 1 - c27 % 3;
                         const int ko = (26 - c27) < 13 ? (26 - c27) : (26 - c27) - 1;   // the plane of the opposite offset
-                        const float* gko = gate + (size_t)ko * g.gps;
+                        const float* gko = gate + (size_t)ko * (size_t)gps_c;
                         const bool rowok = z + dz >= 0 && z + dz < g.D && y + dy >= 0 && y + dy < g.H;
-                        const int sh = ((dz * g.H + dy) * g.W) * 4;
+                        const int sh = ((dz * Hc + dy) * Wc) * 4;
                         // first / last element outside the volume: read the aligned quad, shift afterwards
                         const int e0 = (dx < 0 && xq0 == 0) || (dx > 0 && xq0 + 4 == g.W) ? 0 : dx * 4;
                         const int e1 = (dx < 0 && xq1 == 0) || (dx > 0 && xq1 + 4 == g.W) ? 0 : dx * 4;
@@ -355,6 +372,47 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 P3_CHUNK(1);
                 __syncthreads();
                 P3_CHUNK(2);
+                for (int ch = 0; ch < nch; ++ch) {
+                if (MULTI && ch > 0) {
+                    // the next value channel on the same (resident) gates: level 0 of channel ch into both level buffers.  The last
+                    // step of the channel before read them without a barrier behind it (as at the top of a chunk)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const float* fb = feat + (size_t)ch * V;
+                    int tid_ = tid;
+                    asm volatile("" : "+v"(tid_));
+                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
+                    const int z = z0 + lz, y = y0 + ly;
+                    int b0, xq0, b1, xq1;
+                    loc(x0 + lx, b0, xq0);
+                    loc(x0 + lx + 4, b1, xq1);
+                    const bool in_zy = z < g.D && y < g.H;
+                    const bool in0 = in_zy && xq0 >= 0 && xq0 + 3 < g.W && b0 < g.B, in1 = in_zy && xq1 >= 0 && xq1 + 3 < g.W && b1 < g.B;
+                    const int row = (z * g.H + y) * g.W;
+                    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 q0 = in0 ? *reinterpret_cast<const float4*>(fb + (unsigned)(b0 * FBS + row + xq0)) : zero4;
+                    const float4 q1 = in1 ? *reinterpret_cast<const float4*>(fb + (unsigned)(b1 * FBS + row + xq1)) : zero4;
+                    const int o = ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
+                    const float own8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        lds[o + i] = own8[i];
+                        lds[LTILE + o + i] = own8[i];
+                    }
+#pragma unroll 1
+                    for (int i = tid_; i < NSH; i += NTP) {
+                        int pz, py, px;
+                        shell_pos(i, pz, py, px);
+                        const int vz = z0 + pz - 1, vy = y0 + py - 1;
+                        int vb, vx;
+                        loc(x0 + px - 1, vb, vx);
+                        const bool ok = vz >= 0 && vz < g.D && vy >= 0 && vy < g.H && vx >= 0 && vx < g.W && vb < g.B;
+                        const float v = ok ? fb[(unsigned)(vb * FBS + (vz * g.H + vy) * g.W + vx)] : 0.f;
+                        lds[(pz * LY + py) * LX + px] = v;
+                        lds[LTILE + (pz * LY + py) * LX + px] = v;
+                    }
+                    __syncthreads();
+                }
                 for (int it = 1; it <= g.n_iter; ++it) {
                     // the 208 gate registers leave no room for loop-invariant addresses: everything below is recomputed from
                     // tid_ each step (a handful of integer instructions) instead of being kept live across the loop
@@ -364,7 +422,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float* cur = lds + ((it - 1) & 1) * LTILE;
                     float* nxt = lds + (it & 1) * LTILE;
                     P3_STAMP(0);
-                    if (NPRE && c + 1 < g.nchunk) {   // one gate plane of the next chunk per step (all of them if there are few steps)
+                    if (NPRE && c + 1 < g.nchunk && (!MULTI || ch == 0)) {   // one gate plane of the next chunk per step (all of them if there are few steps)
 #pragma unroll 1
                         for (int k = it - 1; k < NPRE / 2; k += g.n_iter) park_gate(c + 1, k, tid_);
                     }
@@ -413,13 +471,13 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         int bb, xx;
                         loc(x, bb, xx);
                         if (xx >= 0 && xx + 3 < g.W && bb < g.B && x >= ox0 && x < ox1)
-                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * (int)V + row + xx)) = r0;
+                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * FBS + row + xx)) = r0;
                         loc(x + 4, bb, xx);
                         if (xx >= 0 && xx + 3 < g.W && bb < g.B && x + 4 >= ox0 && x + 4 < ox1)
-                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * (int)V + row + xx)) = r1;
+                            *reinterpret_cast<float4*>(dst + (unsigned)(bb * FBS + row + xx)) = r1;
                     };
                     if (it == g.n_iter) {
-                        store_owned(out);
+                        store_owned(MULTI ? out + (size_t)ch * V : out);
                         break;
                     }
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
@@ -429,7 +487,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     P3_STAMP(1);
                     // publications are numbered through the whole launch and alternate between the two buffers, so the
                     // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
-                    const unsigned target = round * (unsigned)(g.n_iter - 1) + (unsigned)it;
+                    const unsigned target = (MULTI ? round * (unsigned)nch + (unsigned)ch : round) * (unsigned)(g.n_iter - 1) + (unsigned)it;
                     {
                         // ---- publish the tile's boundary straight from the registers as self-validating 16-byte quads (up to three
                         // values + the step tag): no wait for the stores, no flag, no barrier -- a reader polls the quad it needs
@@ -539,13 +597,21 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                         if (lost) {
                             *err = 2;
-                            if (g.status) __hip_atomic_store(g.status, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            {   // the device's sticky status word <- this launch's number.  Both come straight out of the kernel-argument
+                                // segment HERE: as ordinary uses of g.status / g.seq they were live (and spilled) across the whole kernel
+                                typedef __attribute__((address_space(4))) const char kchar;   // (constant address space: scalar loads, no flat access)
+                                kchar* ka = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+                                const unsigned seq_ = *(__attribute__((address_space(4))) const volatile unsigned*)(ka + GEO3_KERNARG_OFFSET + offsetof(Geo3, seq));
+                                unsigned* const st_ = *(unsigned* __attribute__((address_space(4))) const volatile*)(ka + GEO3_KERNARG_OFFSET + offsetof(Geo3, status));
+                                if (st_) __hip_atomic_store(st_, seq_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
                             s_bail = 1;
                         }
                     }
                     __syncthreads();
                     P3_STAMP(4);
                 }
+                }   // value channel
                 P3_CHUNK(3);
             }
         }
@@ -628,8 +694,9 @@ size_t persistent3d_workspace(int B, int D, int H, int W) {
 // adjoint: the transposed operator (backward); levels: volume lv0 + it * lvs receives the result of step it < n_iter;
 // cprime != nullptr: gate holds the 26 folded planes [26][B][V] and cprime the constant term (normalising / masked modes)
 static int persistent3d_launch(const float* gate, const float* feat, const float* cprime, float* out, float* levels, int lv0, int lvs,
-                               bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt) {
+                               bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt, int C = 1) {
     Geo3 g = make_geo3(B, D, H, W, n_iter);
+    g.C = C;
     g.lv0 = lv0;
     g.lvs = lvs;
     const size_t total = (size_t)B * D * H * W;
@@ -666,6 +733,7 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
                    : adjoint ? (const void*)cspn3d_persistent_kernel<true, false>
+                   : C > 1 ? (const void*)cspn3d_persistent_kernel<false, false, false, true>
                    : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
     const bool coop = opt.coop;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -716,6 +784,16 @@ int persistent3d_run(const float* gate, const float* feat, float* out, float* le
 int persistent3d_forward_folded(const float* wf, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                                 hipStream_t st) {
     return persistent3d_launch(wf, feat, wf + 26 * (size_t)B * D * H * W, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st, P3Options());
+}
+
+// C value channels per volume on shared gates (feat, out: [B][C][V]; the Paddle contract): one gate load per chunk for all of them
+bool persistent3d_multi_supported(int B, int C, int D, int H, int W, int n_iter) {
+    return C >= 1 && persistent3d_supported(B, D, H, W, n_iter) && (long long)B * C * D * H * W * 4 < (1LL << 32);
+}
+
+int persistent3d_forward_multi(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter, void* ws,
+                               hipStream_t st) {
+    return persistent3d_launch(gate, feat, nullptr, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st, P3Options(), C);
 }
 
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,

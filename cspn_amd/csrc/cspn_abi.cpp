@@ -251,6 +251,28 @@ int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* s
     return stepwise3d_forward(gate, feat, sparse, out, B, D, H, W, n_iter, norm_type, ws, st, algo);
 }
 
+int cspn3d_multi_supported(int B, int C, int D, int H, int W, int n_iter) {
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return persistent3d_multi_supported(B, C, D, H, W, n_iter) ? 1 : 0;
+}
+
+int cspn3d_forward_multi_f32(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter,
+                             void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (B < 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d C=%d D=%d H=%d W=%d", B, C, D, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if (int e = async_failure_of_earlier_call()) return e;
+    if (int e = check_common(gate, feat, out, n_iter, CSPN_NORM_NONE, ws, ws_bytes,
+                             n_iter == 0 ? 0 : forward3d_workspace(B, D, H, W, n_iter, CSPN_NORM_NONE, false))) return e;
+    const bool aligned = ((((uintptr_t)gate | (uintptr_t)feat | (uintptr_t)out | (uintptr_t)ws) & 15u) == 0);
+    if (!aligned || !persistent3d_multi_supported(B, C, D, H, W, n_iter)) {
+        set_error("cspn3d_forward_multi_f32 runs the persistent kernel only (W %% 4 == 0, 2 <= n_iter <= 60, 16-byte aligned tensors, "
+                  "volume resident on the device): loop over the channels with cspn3d_forward_f32 for B=%d C=%d D=%d H=%d W=%d n_iter=%d",
+                  B, C, D, H, W, n_iter);
+        return CSPN_E_UNSUPPORTED;
+    }
+    return persistent3d_forward_multi(gate, feat, out, B, C, D, H, W, n_iter, ws, (hipStream_t)stream);
+}
+
 size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     return backward3d_workspace(B, D, H, W, n_iter);

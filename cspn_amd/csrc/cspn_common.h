@@ -51,6 +51,10 @@ struct P3Options { int mute = -1; bool coop = false; };
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
                      int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt = P3Options());
 int persistent3d_error_word(const void* ws, int B, int D, int H, int W);
+// C value channels per volume that share the gates ([B][C][V] value tensors, [B][26][V] gates used as given)
+bool persistent3d_multi_supported(int B, int C, int D, int H, int W, int n_iter);
+int persistent3d_forward_multi(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter, void* ws,
+                               hipStream_t st);
 
 // sticky per-device status of the persistent launches: != 0 once after a launch gave up (a workgroup waited in vain for a
 // neighbour: not all workgroups resident); read without synchronisation from a pinned host word, cleared by the read

@@ -189,6 +189,29 @@ def cspn3d_forward(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs", alg
     return (out, ws) if _return_ws else out
 
 
+def cspn3d_forward_multi(gate, feat, n_iter=12):
+    """gate [B,26,D,H,W] (used as given: the Paddle contract), feat [B,C,D,H,W] -> [B,C,D,H,W]: the C channels share the gates
+    (reference cspn_paddle/README.md:56), which are read once per forward and stay in the registers while the n_iter steps run for
+    one channel after the other.  Raises CspnError where the persistent kernel does not take the call (see cspn3d_multi_supported)."""
+    lib = _lib.load()
+    if gate.dim() != 5 or gate.shape[1] != 26:
+        raise ValueError("gate must be [B,26,D,H,W], got %s" % (tuple(gate.shape),))
+    B, _, D, H, W = gate.shape
+    C = feat.shape[1]
+    g = _prep(gate, "gate")
+    h = _prep(feat, "feat", (B, C, D, H, W))
+    out = torch.empty_like(h)
+    if B == 0:
+        return out
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, int(n_iter), _lib.NORM_TYPES["none"], 0)
+        ws = _workspace(ws_bytes, g.device)
+        rc = lib.cspn3d_forward_multi_f32(g.data_ptr(), h.data_ptr(), out.data_ptr(), B, C, D, H, W, int(n_iter), ws.data_ptr(), ws_bytes,
+                                          torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn3d_forward_multi_f32")
+    return out
+
+
 def cspn3d_check_status(device=None):
     """Synchronises the current stream of `device` and raises CspnError if a persistent 3D launch gave up on it (its outputs are
     NaN-filled): the failure the C ABI can only report after the call has returned.  Every later cspn3d_* call raises it too
@@ -262,6 +285,10 @@ def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
     if gate_weight.shape[1] != 3 ** d - 1:
         raise ValueError("gate_weight must have %d channels" % (3 ** d - 1))
     N, C = input.shape[:2]
+    needs_grad = torch.is_grad_enabled() and (input.requires_grad or gate_weight.requires_grad)
+    if d == 3 and C > 1 and not needs_grad and input.is_cuda and _lib.load().cspn3d_multi_supported(N, C, *input.shape[2:], int(n_iter)) \
+            and input.is_contiguous() and gate_weight.is_contiguous() and input.data_ptr() % 16 == 0 and gate_weight.data_ptr() % 16 == 0:
+        return cspn3d_forward_multi(gate_weight, input, n_iter)   # the gates are read once for all C channels
     outs = []
     for c in range(C):  # gates shared across channels (README.md:56)
         x = input[:, c:c + 1].contiguous()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 2   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex */
+#define CSPN_ABI_VERSION 3   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32 */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -161,6 +161,16 @@ int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* s
  * grad_gate [B,26,D,H,W] and grad_feat [B,1,D,H,W] are outputs, either may be NULL.  n_iter chained steps with the same
  * gates are differentiated as one op (n_iter = 1 is the single fluid.layers.affinity_propagate call). */
 size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
+/* C input channels on SHARED gates (reference cspn_paddle/README.md:56: "gate_weight would be shared in the channel dimension for
+ * input when C>1"; call site demo.py:41-43): feat, out [B,C,D,H,W], gate [B,26,D,H,W] used as given (norm NONE, no mask), n_iter
+ * chained steps.  The gates of a chunk are read ONCE and stay in the registers while the steps run for channel after channel
+ * (a per-channel loop over cspn3d_forward_f32 reads the 104 B/voxel of gates C times).  cspn3d_multi_supported() != 0 where the
+ * persistent kernel takes the call (W % 4 == 0, 2 <= n_iter <= 60, 16-byte aligned tensors, the volume fits the device);
+ * elsewhere the entry point returns CSPN_E_UNSUPPORTED and the caller loops over the channels.  Workspace:
+ * cspn3d_workspace_bytes_ex(B, D, H, W, n_iter, CSPN_NORM_NONE, 0).  Same failure reporting as above (CSPN_E_ASYNC). */
+int cspn3d_multi_supported(int B, int C, int D, int H, int W, int n_iter);
+int cspn3d_forward_multi_f32(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter,
+                             void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat,
                         int B, int D, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);

@@ -51,7 +51,7 @@ def _run(g, h, s, N, norm, algo):
 
 def test_library_is_loaded_and_gpu_present():
     assert torch.cuda.is_available()
-    assert cspn_amd.load().cspn_abi_version() == 2
+    assert cspn_amd.load().cspn_abi_version() == 3
 
 
 def test_golden_vectors(golden):
@@ -308,6 +308,27 @@ def test_3d_persistent_vs_stepwise_and_oracle(B, D, H, W, N):
     assert torch.equal(a, cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent"))   # deterministic
     if B * D * H * W <= 400000:
         assert_close(a.cpu().numpy(), cspn3d_oracle(g.cpu(), h.cpu(), None, N, "none"), "3d persistent")
+
+
+@pytest.mark.parametrize("B,C,D,H,W,N", [(1, 3, 16, 24, 128, 6), (2, 2, 10, 9, 68, 4), (1, 3, 32, 160, 152, 12), (3, 4, 8, 16, 64, 2)])
+def test_3d_shared_gates_multi_channel_equals_per_channel_loop(B, C, D, H, W, N):
+    """round 4: C input channels on shared gates (reference cspn_paddle/README.md:56) in ONE persistent launch -- the gates of a chunk
+    are loaded once and stay in the registers while the steps run for channel after channel -- against C single-channel calls,
+    bit for bit; cspn_amd.affinity_propagate takes that path for C > 1"""
+    gen = torch.Generator(device=DEV).manual_seed(B * 100 + C * 10 + N)
+    g = torch.rand(B, 26, D, H, W, generator=gen, device=DEV)
+    g /= g.sum(1, keepdim=True)
+    x = torch.rand(B, C, D, H, W, generator=gen, device=DEV) * 80
+    assert cspn_amd.load().cspn3d_multi_supported(B, C, D, H, W, N)
+    got = cspn_amd.cspn3d_forward_multi(g, x, N)
+    ref = torch.cat([cspn_amd.cspn3d_forward(g, x[:, c:c + 1].contiguous(), None, N, "none", algo="persistent") for c in range(C)], 1)
+    cspn_amd.cspn3d_check_status()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)
+    with torch.no_grad():
+        assert torch.equal(cspn_amd.affinity_propagate(x, g, 3, N), ref)
+    if B * D * H * W <= 100000:
+        assert_close(got[:, 1:2].cpu().numpy(), cspn3d_oracle(g.cpu(), x[:, 1:2].cpu(), None, N, "none"), "3d multi, channel 1")
 
 
 def test_3d_config5_full_size_persistent_vs_stepwise_every_voxel():
