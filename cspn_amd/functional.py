@@ -115,8 +115,10 @@ def cspn2d_history_bytes(B, H, W, n_iter):
 
 
 def cspn2d_forward_with_history(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum"):
-    """Training-mode forward: same output as cspn2d_forward, plus an opaque `history` tensor (every intermediate level and
-    the folded coefficients) for cspn2d_backward_from_history.  Only where cspn2d_history_bytes(...) > 0."""
+    """Training-mode forward: same output as cspn2d_forward, plus an opaque `history` tensor for cspn2d_backward_from_history:
+    the checkpoints H_4, H_8 .. H_20 (every fourth level, register order per 4-column group) followed by the 8 folded coefficient
+    planes -- 13 planes of B*H*W floats (the backward recomputes the levels in between; a tensor in the round-2 format, all 23
+    levels, is NOT accepted: its size differs and the size is checked).  Only where cspn2d_history_bytes(...) > 0."""
     lib = _lib.load()
     B, _, H, W = guidance.shape
     g = _prep(guidance, "guidance", (B, 8, H, W))

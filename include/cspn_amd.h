@@ -149,8 +149,10 @@ enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 
  * a compute unit (another process, a CU mask, a long kernel of another library on the device), the waiting ones give up after
  * ~0.5 s, fill the voxels they own with NaN -- the call's `out` then never passes for a result -- and raise a sticky per-device
  * status word.  The NEXT cspn3d_* call of the process on that device (forward or backward, any stream) finds it without a
- * synchronisation, returns CSPN_E_ASYNC instead of enqueuing anything, and clears it.  cspn3d_check_status synchronises
- * `stream` first, so it also reports the call just made: 0, CSPN_E_ASYNC or a hipError_t. */
+ * synchronisation, returns CSPN_E_ASYNC instead of enqueuing anything (the reporting call itself is NOT run: call again), and
+ * remembers that this launch has been reported: the status word holds the NUMBER of the launch that gave up, so the same
+ * launch's other workgroups, which run into their own timeouts later, do not produce a second report.  cspn3d_check_status
+ * synchronises `stream` first, so it also reports the call just made: 0, CSPN_E_ASYNC or a hipError_t. */
 int cspn3d_check_status(cspn_stream_t stream);
 int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
