@@ -98,3 +98,30 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_reductions_survive_a_failing_collective():
+    """bench.py must print its throughput line even if a collective misbehaves on the day the driver's 8-GPU run happens: the timing
+    reductions fall back to rank 0's own values and say so (round-3 review, item 6)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class BrokenDist(object):
+        class ReduceOp(object):
+            MAX = "max"
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            raise RuntimeError("NCCL error: unhandled system error (simulated)")
+
+        @staticmethod
+        def barrier():
+            raise RuntimeError("barrier timed out (simulated)")
+
+    notes = []
+    assert bench._reduce(BrokenDist, [1.5, 2.5], BrokenDist.ReduceOp.MAX, "cpu", True, notes) == [1.5, 2.5]
+    bench._barrier(BrokenDist, notes)
+    assert len(notes) == 2 and "all_reduce failed" in notes[0] and "simulated" in notes[0] and "barrier failed" in notes[1]
+    assert bench._reduce(None, [3.0], None, "cpu", True, notes) == [3.0] and len(notes) == 2   # single process: no collective at all

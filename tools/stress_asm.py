@@ -13,29 +13,28 @@ import cspn_amd  # noqa: E402
 def main():
     torch.manual_seed(0)
     bad = 0
-    lib = cspn_amd.load()
-    for (B, H, W, sp, loop) in [(8, 304, 1216, True, 3), (64, 304, 1216, False, 3), (64, 304, 1216, True, 2), (16, 228, 304, True, 3),
-                                (3, 57, 260, False, 3), (16, 228, 304, True, 2)]:
-        lib.cspn_debug_tsw_loop(loop)   # 2: round-2 loop, 3: round-3 loop (LDS-DMA: a missing wait / barrier would flicker)
+    from tools.fuzz_parity import forward2d_plan
+    for (B, H, W, sp, loop) in [(8, 304, 1216, True, 0), (64, 304, 1216, False, 0), (64, 304, 1216, True, 2), (16, 228, 304, True, 0),
+                                (3, 57, 260, False, 0), (16, 228, 304, True, 1), (7, 150, 516, True, 0)]:
+        # loop = plan of the assembly passes: 0 the product's linear plan, 1 without XCD-aware placement, 2 band groups
         gen = torch.Generator(device="cuda").manual_seed(B + W)
         g = torch.randn(B, 8, H, W, generator=gen, device="cuda")
         h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
         s = (torch.rand(B, 1, H, W, generator=gen, device="cuda") < 0.01).float() * (h + 0.1) if sp else None
         go = torch.randn(B, 1, H, W, generator=gen, device="cuda")
-        ref = cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused")
+        ref = forward2d_plan(g, h, s, 24, "8sum", loop)
         cxx = cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused_cxx")
         d = float((ref - cxx).abs().max() / cxx.abs().max())
         gg0, gh0 = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
         flick = 0
         for i in range(40):
-            o = cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused")
+            o = forward2d_plan(g, h, s, 24, "8sum", loop)
             flick += int(not torch.equal(o, ref))
             if i % 8 == 0:
                 gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
                 flick += int(not torch.equal(gg, gg0)) + int(not torch.equal(gh, gh0))
         torch.cuda.synchronize()
-        lib.cspn_debug_tsw_loop(0)
-        print("B%d %dx%d sparse=%s loop %d: asm vs compiled %.2e, non-identical repeats %d" % (B, H, W, sp, loop, d, flick), flush=True)
+        print("B%d %dx%d sparse=%s plan mode %d: asm vs compiled %.2e, non-identical repeats %d" % (B, H, W, sp, loop, d, flick), flush=True)
         bad += flick + int(d > 1e-5)
     print("STRESS", "OK" if bad == 0 else "FAILED")
     return bad
