@@ -66,6 +66,9 @@ def parse():
                     help="profiling runs: one torch elementwise kernel over the depth batch before the loop (known byte count, "
                          "calibrates FETCH_SIZE / WRITE_SIZE in the same rocprofv3 trace)")
     ap.add_argument("--no-broadcast", action="store_true")
+    ap.add_argument("--event-every", type=int, default=1,
+                    help="bracket every N-th timed launch with a HIP event pair (1: every launch).  Event records between kernels cost "
+                         "inter-kernel gap (wall time per step), not kernel time; the reported device time is the mean over the bracketed launches")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="N > 1, weak scaling: do not also time BASELINE config 3 as written (--global-batch images sharded over the ranks)")
     ap.add_argument("--plan-mode", type=int, default=0, choices=[0, 1, 2, 3],
@@ -172,12 +175,15 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    every = max(1, int(a.event_every))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(steps)]
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
+    for ev in evs:
+        if ev is not None:
+            ev[0].record(stream)
         step()
-        e1.record(stream)
+        if ev is not None:
+            ev[1].record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -339,17 +345,20 @@ def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, 
     _barrier(dist, notes)
     torch.cuda.synchronize()
     # per-launch device time: HIP events on the stream the kernels are launched on
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    every = max(1, int(a.event_every))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(steps)]
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
+    for ev in evs:
+        if ev is not None:
+            ev[0].record(stream)
         step()
-        e1.record(stream)
+        if ev is not None:
+            ev[1].record(stream)
     torch.cuda.synchronize()
     _barrier(dist, notes)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    dev_ms = sorted(ev[0].elapsed_time(ev[1]) for ev in evs if ev is not None)
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
     par = None
     if parity:
