@@ -721,8 +721,13 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     Dev3& d = dev3();
     if (!d.status_host) {   // first launch on this device: one pinned word; its device address travels as a kernel argument, so
         // nothing here touches a stream (no symbol copy, no implicit synchronisation: safe under stream capture)
+        // (a pinned allocation is an "unsafe" call while some stream of the thread is being captured in the default global mode: it
+        // would invalidate the capture -- the documented way for a library to allocate regardless is the relaxed mode, for the call)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         e = hipHostMalloc((void**)&d.status_host, 64, hipHostMallocMapped);
         if (e == hipSuccess) { *d.status_host = 0; e = hipHostGetDevicePointer((void**)&d.status_dev, d.status_host, 0); }
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         if (e != hipSuccess) { set_error("status word of the persistent kernel: %s", hipGetErrorString(e)); d.status_host = nullptr; return (int)e; }
     }
     const int mute = opt.mute;

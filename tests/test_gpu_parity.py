@@ -607,3 +607,35 @@ def test_forward_paths_can_be_captured_in_a_graph():
         torch.cuda.synchronize()
         assert torch.equal(o2, cspn_amd.cspn2d_forward(g, h, None, 24, "8sum"))
         assert torch.equal(o3, cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="stepwise"))
+
+
+@pytest.mark.gpu
+def test_first_persistent_launch_of_a_process_can_be_captured():
+    """round-3 advisor finding: the first persistent 3D launch on a device used to copy the status pointer into a __device__ symbol
+    (a blocking copy on the null stream: it invalidates a capture).  The pointer is a kernel argument now, so a process whose FIRST
+    persistent launch happens inside a graph capture works -- checked in a fresh process (this one has launched the kernel already)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import torch, cspn_amd
+gen = torch.Generator(device="cuda").manual_seed(5)
+g3 = torch.rand(1, 26, 16, 24, 128, generator=gen, device="cuda"); g3 /= g3.sum(1, keepdim=True)
+h3 = torch.rand(1, 1, 16, 24, 128, generator=gen, device="cuda")
+# one call of ANOTHER kernel of the library first: the HIP runtime loads a library's code object at its first launch, which is not
+# capturable for any library; what is under test is the persistent launch's own first-time host work (its status word)
+cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="stepwise")
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    o3 = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="persistent")   # the process's first launch of the kernel
+graph.replay(); torch.cuda.synchronize()
+ref = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="stepwise")
+cspn_amd.cspn3d_check_status()
+assert torch.equal(o3, ref), float((o3 - ref).abs().max())
+print("CAPTURE_OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURE_OK" in r.stdout, r.stderr[-3000:]
