@@ -639,3 +639,44 @@ print("CAPTURE_OK")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and "CAPTURE_OK" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_host_threads_call_the_library_concurrently():
+    """the boundary promises re-entrancy (nn.DataParallel calls replicas from several Python threads, reference cspn_pytorch/eval.py:117):
+    four host threads, each on its own stream, run the 2D forward (different shapes: each thread has its own plan cache), the 3D
+    persistent kernel (launches chained across threads) and the error path at the same time; every result equals the serial one"""
+    import threading
+    shapes = [(3, 120, 516), (2, 304, 1216), (5, 77, 304), (1, 60, 772)]
+    gen = torch.Generator(device=DEV).manual_seed(404)
+    ins = [(torch.randn(B, 8, H, W, generator=gen, device=DEV), torch.rand(B, 1, H, W, generator=gen, device=DEV) * 80) for B, H, W in shapes]
+    g3 = torch.rand(1, 26, 16, 24, 128, generator=gen, device=DEV)
+    g3 /= g3.sum(1, keepdim=True)
+    h3 = torch.rand(1, 1, 16, 24, 128, generator=gen, device=DEV)
+    ref2 = [cspn_amd.cspn2d_forward(g, h, None, 24, "8sum") for g, h in ins]
+    ref3 = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="persistent")
+    torch.cuda.synchronize()
+    errors, lib = [], cspn_amd.load()
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(6):
+                    g, h = ins[(i + rep) % len(ins)]
+                    o2 = cspn_amd.cspn2d_forward(g, h, None, 24, "8sum")
+                    o3 = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="persistent")
+                    rc = lib.cspn2d_forward_f32(None, None, None, None, 1, 4, 4, 3, 0, None, 0, None)   # thread-local error message
+                    assert rc == -1 and b"null" in lib.cspn_last_error()
+                    st.synchronize()
+                    assert torch.equal(o2, ref2[(i + rep) % len(ins)]) and torch.equal(o3, ref3)
+        except BaseException as ex:   # noqa: BLE001 -- reported to the main thread
+            errors.append("thread %d: %r" % (i, ex))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    cspn_amd.cspn3d_check_status()
+    assert not errors, errors
