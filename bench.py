@@ -101,10 +101,12 @@ def synth(B, H, W, scale, sparse, device, first=0, seed0=1000):
 
 def parity_check(out, g, h, s, n_iter, norm, rtol=1e-4):
     """after the timed region: the oracle (CPU port of reference cspn.py, test infrastructure) on a sample of this rank's
-    batch -- first, middle and last image -- against what the timed launches left in `out`."""
+    batch -- the first image, the two in the middle (at 64 images: 31, which the plan cuts in the middle between two workgroups,
+    and 32, which it does not) and the last one (whose bands the last four CUs share) -- against what the timed launches left in
+    `out`."""
     from oracle import cspn2d_oracle
     B = out.shape[0]
-    idx = sorted({0, B // 2, B - 1})
+    idx = sorted({0, max(0, B // 2 - 1), B // 2, B - 1})
     ref = cspn2d_oracle(g[idx].cpu(), h[idx].cpu(), None if s is None else s[idx].cpu(), n_iter, norm)
     ref = torch.from_numpy(ref) if not isinstance(ref, torch.Tensor) else ref
     got = out[idx].cpu()
