@@ -388,10 +388,15 @@ class Gen(object):
         if not skip_above1:
             self.push_above(1, v0, D_TAIL, ACC(p, 1), init=WT(1, 8))
 
-    def step(self, c, slow=False):
+    def step(self, c, slow=False, hi=False):
         """Round 3: two bodies per counter -- the fast one assumes that all four slots hold real rows (vcc == 0) and carries no
         per-slot checks; `slow` (out of line, entered by one branch at the top of the fast body) pins slots that hold a
-        separator / padding row to zero."""
+        separator / padding row to zero.
+        cfg stagger (round 4): the loop exists in two flavours; waves 0..3 run the `lo` one (they cook rows 0, 1 of a group, at
+        counters = 2 mod 3), waves 4..7 the `hi` one (rows 2, 3, which enter a step later: cooked at counters = 0 mod 3), so
+        that the two waves of a SIMD (w and w + 4) never cook -- scalar / LDS / vector-memory instructions, which only issue for
+        free beside the partner's VALU work -- in the same step."""
+        LS = ".LH" if hi else ".LS"
         act_fast = self.cfg.get("act_and", True) and not self.elastic and "noact" not in self.ab
         p = c & 1
         N1 = [ACC(p, j) for j in range(4)]
@@ -403,9 +408,9 @@ class Gen(object):
         # cooking: the group of four rows that enters from step 3*gamma on is cooked at step 3*gamma - 1 (counter % 3 == 2).
         # stagger: its last two rows (tasks of waves 4..7) only enter at 3*gamma + 1 / + 2, so those waves cook one step
         # later: of the two waves that share a SIMD never both cook (and queue their loads) in the same step
-        stag = self.cfg.get("stagger", False)   # measured: 1 % slower than cooking in lock step
-        cook = (c % 3 == 2 or (stag and c % 3 == 0)) and "nocook" not in self.ab
-        cook_hi = stag and c % 3 == 0          # this variant cooks the tasks of waves 4..7
+        stag = self.cfg.get("stagger", False)
+        assert stag or not hi
+        cook = (c % 3 == (0 if hi else 2)) and "nocook" not in self.ab
         g = (((c + 1) // 3) if c % 3 == 2 else (c // 3)) & 1
         # cook_early: the pending task is normalised and written to the ring at the END of the step before (counter % 3 == 1),
         # behind the chain, where every wave but the one with an event has slack before the barrier; the step with
@@ -414,26 +419,17 @@ class Gen(object):
         cook_math_here = cook and not early
         cook_at_end = early and c % 3 == 1
 
-        def guard():
-            """-> label to jump to for the waves that do not cook in this variant"""
-            if not stag:
-                return None
-            lab = self.p.newlabel("nocook")
-            self.e("s_bitcmp1_b32", (), [S_WV, 2])
-            self.e("s_cbranch_scc0" if cook_hi else "s_cbranch_scc1", (), [lab])
-            return lab
         if slow:
-            self.p.label(".LSs%d_%%=" % c)
+            self.p.label(LS + "s%d_%%=" % c)
         else:
-            self.p.label(".LS%d_%%=" % c)
+            self.p.label(LS + "%d_%%=" % c)
             if act_fast:
-                self.e("s_cbranch_vccnz", (), [".LSs%d_%%=" % c])
+                self.e("s_cbranch_vccnz", (), [LS + "s%d_%%=" % c])
         # an event makes this wave the slowest of the step while the wave it shares its SIMD with has slack: let it issue first
         prio = self.cfg.get("prio", 1) if ev is not None else 0
         if prio:
             self.e("raw", (), ["s_setprio %d" % prio])
         self.probe(0)
-        assert not stag, "the stagger option was dropped (measured 1 % slower)"
         partial = self.cfg.get("partial_wait", True) and not self.cfg.get("trace", False)
         # slim events: the H0 quad read for the row entering slot ev is, one step later, the "row above" of the row entering
         # slot ev + 1 (a wave's four events are consecutive steps): two quads alternate, nothing is read twice; and slots
@@ -557,7 +553,7 @@ class Gen(object):
         self.e("s_sub_u32", S_TAU, [S_TAU, 1])           # S_TAU counts the remaining steps down; the borrow ends the loop
         self.e("s_cbranch_scc1", (), [".Lexit_%="])
         if slow or c == LV - 1:
-            self.e("s_branch", (), [".LS%d_%%=" % ((c + 1) % LV)])
+            self.e("s_branch", (), [LS + "%d_%%=" % ((c + 1) % LV)])
 
     # ---------------------------------------------------------------------------------- cfg elastic: tags instead of the barrier
     def tag_reads(self, c, p, ev, stub=False):
@@ -1143,17 +1139,24 @@ class Gen(object):
         for w in range(NW):
             c0 = (LV - 3 * w) % LV
             e("s_cmp_eq_u32", (), [S_WV, w])
-            e("s_cbranch_scc1", (), [".LS%d_%%=" % c0])
+            e("s_cbranch_scc1", (), [(".LH" if self.cfg.get("stagger", False) and w >= NW // 2 else ".LS") + "%d_%%=" % c0])
 
     def build(self):
         self.prologue()
+        stag = self.cfg.get("stagger", False)
         for c in range(LV):
             self.step(c)
+        if stag:
+            for c in range(LV):
+                self.step(c, hi=True)
         self.p.label(".Lexit_%=")
         self.e("s_branch", (), [".Lend_%="])
         if self.cfg.get("act_and", True) and not self.elastic and "noact" not in self.ab:
             for c in range(LV):
                 self.step(c, slow=True)
+            if stag:
+                for c in range(LV):
+                    self.step(c, slow=True, hi=True)
         for st in self.estubs:
             self.emit_tag_stub(*st)
         if self.elastic:

@@ -11,7 +11,7 @@ from .plan import build_plan
 
 
 def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False, hist_every=1,
-             s8=False, elastic=False, sched_seed=None, linear=None):
+             s8=False, elastic=False, sched_seed=None, linear=None, cfg_extra=None):
     """linear = number of CUs: the forward passes' linear plan (tools/tswgen/plan.py LinearPlan: one contiguous piece of the
     band-row order per CU; a piece may continue in the next band) instead of band groups"""
     sys.path.insert(0, ".")
@@ -33,7 +33,8 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     if hin:  # emulate a second pass: level-0 values differ from blur
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
     K.configure(elastic)
-    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, hist_every=hist_every, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {})), sched=sched)
+    prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, hist_every=hist_every, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {}),
+                        **(cfg_extra or {})), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
