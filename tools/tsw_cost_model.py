@@ -111,6 +111,9 @@ def main():
     row("half-step phase shift between neighbouring waves (to take the LDS round trip off the critical path)", S_new, I,
         "**impossible**: a lead of 1/2 step per wave is 4 steps around the ring of 8: a wave would get its next four rows every 20 steps while a "
         "row lives 24 (the ring is exactly full)", None, -C_SYNC)
+    row("SIMD partners cook in different steps (generator option `stagger`: waves 0..3 at counters = 2 mod 3, waves 4..7 at 0 mod 3), hoping their "
+        "non-VALU instructions issue beside the partner's FMAs", S_new, I, "**built and measured: +0.6 %** (0.2775 vs 0.2757 ms, profiles/r04_stagger_ab.md): the "
+        "same instructions per SIMD and three steps either way", "0.2769-0.2786")
     row("floor of this ring: only the chain (64 v_pk_fma_f32 + 12 DPP moves per wave-step), cooking / events / feed free", S_new, chain,
         "what no pipeline around the ring can beat")
     print("# r04 — time model of the fused 2D forward and what it says about other decompositions\n")
