@@ -132,3 +132,22 @@ def test_cxx_planner_matches_the_numpy_twin(B, H, W, ncu):
     lp = LinearPlan(B, H, W, 24, ncu)
     assert n == lp.n_wg and kimg.value == lp.kimg and stride.value == lp.stride
     assert list(cut[:n + 1]) == lp.cut
+
+
+def test_library_plan_cache_returns_the_right_plan_after_evictions():
+    """the library keeps the last four forward plans per host thread (the optimiser costs ~1 ms): six shapes visited twice in a
+    row-robin must each get their own plan every time (cspn_debug_tsw_plan_geo goes through the cached entry point; no GPU: the CU
+    count defaults to 256)"""
+    import ctypes
+    from cspn_amd import _lib
+    hooks = _lib.load_hooks()
+    shapes = [(64, 304, 1216), (16, 228, 304), (3, 33, 304), (8, 304, 1216), (5, 77, 772), (2, 100, 1216)]
+    seen = {}
+    for rnd in range(2):
+        for B, H, W in shapes:
+            info = (ctypes.c_int * 8)()
+            assert hooks.cspn_debug_tsw_plan_geo(B, H, W, 0, 0, info) == 0
+            lp = LinearPlan(B, H, W, 24, 256)
+            got = tuple(info)
+            assert got[:4] == (1, lp.n_wg, lp.stride, lp.kimg), (B, H, W, got)
+            assert seen.setdefault((B, H, W), got) == got

@@ -185,3 +185,11 @@ def test_emulated_elastic_loop_vs_oracle(sched_seed):
     err, nanmis, out, ref = run_case(2, 17, 304, 5, 0, True, False, seed=5, zero_patch=True, verbose=False, elastic=True,
                                      sched_seed=sched_seed)
     assert nanmis == 0 and err <= 1e-4 and np.isnan(ref).any()
+
+
+def test_emulated_staggered_cooking_option():
+    """generator option stagger (round 4: the two waves of a SIMD cook in different steps; two flavours of the loop): measured no
+    faster and not in the product (profiles/r04_stagger_ab.md), but kept working"""
+    os.chdir(ROOT)
+    err, nanmis, _, ref = run_case(2, 17, 304, 5, 0, True, False, seed=9, zero_patch=True, verbose=False, cfg_extra=dict(stagger=True))
+    assert nanmis == 0 and err <= 1e-4 and np.isnan(ref).any()
