@@ -54,3 +54,22 @@ def test_planner_covers_every_pixel_once():
                     assert p0 + tm.BW - hi >= N  # right halo deep enough
                 cover[b, y0:y1, lo:hi] += 1
         assert (cover == 1).all()
+
+
+def test_cost_model_reproduces_the_two_measured_plans():
+    """tools/tsw_cost_model.py (profiles/r04_decomposition_model.md): time = steps x (instructions per SIMD-step x 5 + 260) cycles /
+    2.15 GHz, with the instruction census of the GENERATED loop and the steps of the PLANNER -- must stay within 3 % of the two plans
+    measured on one MI355X in round 4 (band groups 0.2905 ms, linear plan 0.2772 ms) when either of them changes"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import tsw_cost_model as M
+    from tools.tswgen.plan import LinearPlan
+    c = M.census(dict(norm=0))
+    I = 2 * sum(c.values())
+    assert 60 <= c["pk_fma"] <= 70 and 240 <= I <= 270, (c, I)
+    s_new = M.steps_of(LinearPlan(64, 304, 1216, 24, 256).L)
+    s_old = M.steps_of(-(-64 * 304 // 42) + 48 + 1)
+    assert (s_old, s_new) == (408, 384)
+    assert abs(M.t_ms(s_old, I) - 0.2905) <= 0.03 * 0.2905
+    assert abs(M.t_ms(s_new, I) - 0.2772) <= 0.03 * 0.2772
