@@ -1,8 +1,8 @@
 """tools/tsw_trace.py -- where does a step of the fused 2D loop spend its cycles?  (run on the GPU box)
 
 Needs a timing-instrumented single-variant build of the library:
-    TSW_CFG="dict(trace=True)" bash tools/build_abl.sh trace ""
-    CSPN_AMD_LIB=$PWD/cspn_amd/abl/libcspn_trace.so python tools/tsw_trace.py [out.json]
+    bash tools/r04/build_trace.sh
+    CSPN_AMD_LIB=$PWD/cspn_amd/abl/trace/libcspn_amd.so python tools/tsw_trace.py [out.json]
 Every wave records six s_memtime stamps per step (shader cycles; the instrumented loop is ~4 % slower than the product loop):
   t0 step start | t1 cooking done (= t0 in steps without cooking) | t2 boundary rows + ring reads arrived
   t3 chain finished, everything issued | t4 own LDS writes landed | t5 barrier released
@@ -61,8 +61,29 @@ def main():
                           ("cook", (c % 3 == 2) & (c >= 4)), ("cook+event", (c % 3 == 2) & (c < 4))):
             if sel.any():
                 kinds[name].append(d[sel].mean(0))
+    # per STEP of a workgroup (one barrier per step): duration = latest barrier release to latest barrier release; how long the
+    # last wave to arrive had been busy; by the kind of step (counter % 3 == 2: every wave cooks)
+    dur_by, busy_by, nsteps_all = {"cook": [], "other": []}, {"cook": [], "other": []}, []
+    for wg in range(0, n_wg, 5):
+        r = raw[wg]
+        nsteps = int((r[:, 0, 0] != 0).sum())
+        nsteps_all.append(nsteps)
+        if nsteps < 50:
+            continue
+        t = r[20:nsteps - 30].astype(np.int64)
+        rel = t[:, :, 5]
+        dur = (rel[1:].max(1) - rel[:-1].max(1)) & 0xffffffff
+        arrive = ((t[1:, :, 4] - t[1:, :, 0]) & 0xffffffff).max(1)
+        is_cook = (t[1:, 0, 6] % 3) == 2
+        for name, sel in (("cook", is_cook), ("other", ~is_cook)):
+            dur_by[name].append(dur[sel].mean())
+            busy_by[name].append(arrive[sel].mean())
     res = {"workload": "KITTI 304x1216 x 64, 24 iterations", "forward_ms_instrumented": round(ms, 4),
-           "mean_cycles_per_step_incl_flush": round(float(np.mean(step_cycles)), 1), "phases": phases, "kinds": {}}
+           "steps_recorded_per_workgroup": [int(min(nsteps_all)), int(max(nsteps_all))],
+           "mean_cycles_per_step_incl_flush": round(float(np.mean(step_cycles)), 1),
+           "step_cycles": {k: round(float(np.mean(v)), 1) for k, v in dur_by.items()},
+           "busiest_wave_cycles": {k: round(float(np.mean(v)), 1) for k, v in busy_by.items()},
+           "phases": phases, "kinds": {}}
     for k, v in kinds.items():
         m = np.mean(v, 0)
         res["kinds"][k] = {"cycles": [round(float(x), 1) for x in m], "total": round(float(m.sum()), 1)}
