@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1, default workload: do not also time BASELINE configs 4, 2, 3-as-written's per-GPU share, 5 and the 2D "
+                         "backward after the headline's timed region (reported under \"configs\")")
     ap.add_argument("--prewarm-s", type=float, default=1.0,
                     help="seconds of untimed launches before the counted warm-up (lets the shader clock settle: the first "
                          "few dozen launches of a process run ~20 %% slower); outside the timed region, reported as prewarm_s")
@@ -122,15 +125,22 @@ def parity_check(out, g, h, s, n_iter, norm, rtol=1e-4):
 
 
 def cpu_baseline(H, W, n_iter, sparse, scale, norm):
-    """The CPU port of the reference path (oracle/cspn_oracle.c, OpenMP over images) on a bounded
-    sample of the same workload, timed on this host's cores."""
+    """Two CPU legs on this host's cores, each on a bounded sample of the same workload:
+    (1) kind "port": oracle/cspn_oracle.c (C restatement of reference cspn.py:42-172, OpenMP over images, one image per thread) on
+        ALL host threads;
+    (2) "reference_op_sequence": tools/torch_ops_baseline.py -- the op sequence reference cspn.py:42-83 launches (eight padded
+        copies + cat, product, 1x1x1 Conv3d channel sum, per iteration), pinned to the unmodified reference's golden vectors by
+        tests/test_oracle.py -- on torch-CPU with all host threads.  /root/reference itself does not exist on the GPU box."""
     from oracle import cspn2d_oracle, oracle_threads, set_oracle_threads
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    set_oracle_threads(threads)
+    set_oracle_threads(cores)
     threads = oracle_threads()
     nimg = threads  # one image per thread per repetition
-    g, h, s = synth(nimg, H, W, scale, sparse, "cpu", first=0, seed0=4242)
+    g, h, s = synth(min(nimg, 64), H, W, scale, sparse, "cpu", first=0, seed0=4242)
+    if nimg > 64:   # (the sample's bits do not matter beyond 64 distinct images: tile them)
+        reps_t = (nimg + 63) // 64
+        g, h = g.repeat(reps_t, 1, 1, 1)[:nimg].contiguous(), h.repeat(reps_t, 1, 1, 1)[:nimg].contiguous()
+        s = s.repeat(reps_t, 1, 1, 1)[:nimg].contiguous() if s is not None else None
     cspn2d_oracle(g[:1], h[:1], None if s is None else s[:1], 1, norm)  # build/load + warm
     reps, t_total = 0, 0.0
     while reps < 3 or (t_total < 4.0 and reps < 20):
@@ -139,7 +149,7 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
         t_total += time.perf_counter() - t0
         reps += 1
     mpix_iters = nimg * H * W * n_iter * reps / 1e6
-    return {
+    res = {
         "value": round(mpix_iters / t_total, 2),
         "unit": "Mpix*iters/s",
         "cores": threads,
@@ -148,21 +158,41 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
                   % (nimg, H, W, n_iter, reps, cores)
                   + "; /root/reference (torch-CPU reference module) does not exist on the GPU box, so the C port stands in for it",
     }
+    try:
+        from tools.torch_ops_baseline import affinity_propagate_torch_ops
+        torch.set_num_threads(cores)
+        nb = 8
+        gb, hb, sb = g[:nb], h[:nb], (s[:nb] if s is not None else None)
+        affinity_propagate_torch_ops(gb[:1], hb[:1], None if sb is None else sb[:1], 2, norm)   # warm (MKL-DNN primitives, thread pool)
+        reps, t_total = 0, 0.0
+        while reps < 2 or (t_total < 6.0 and reps < 10):
+            t0 = time.perf_counter()
+            affinity_propagate_torch_ops(gb, hb, sb, n_iter, norm)
+            t_total += time.perf_counter() - t0
+            reps += 1
+        res["reference_op_sequence"] = {
+            "value": round(nb * H * W * n_iter * reps / 1e6 / t_total, 2), "unit": "Mpix*iters/s", "cores": torch.get_num_threads(),
+            "kind": "reference_op_sequence",
+            "sample": "%d images %dx%d x %d iters x %d reps, tools/torch_ops_baseline.py (the torch op sequence of reference cspn.py:42-83 "
+                      "incl. its 1x1x1 Conv3d channel sum, pinned to the unmodified reference's golden vectors) on torch-CPU %s, "
+                      "torch.set_num_threads(%d)" % (nb, H, W, n_iter, reps, torch.__version__, cores)}
+    except Exception as ex:   # noqa: BLE001 -- reported in the line, never hidden
+        res["reference_op_sequence"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    return res
 
 
-def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
-    """BASELINE config 5: 3x3x3 propagation, 12 iterations, 32x160x608 volume, batch 4 per GPU, gates normalised by the
+def measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, steps, warmup, prewarm_s, cpu_base=False):
+    """BASELINE config 5: 3x3x3 propagation, 12 iterations, 32x160x608 volume, batch B per GPU, gates normalised by the
     caller and used as given (the fluid.layers.affinity_propagate contract, reference cspn_paddle/demo.py:41-52).
-    --algo auto / fused: the persistent kernel (gates resident in registers across all steps: one pass over the 104 B/voxel
-    gate tensor per forward); --algo stepwise: one step3d_direct_kernel launch per iteration."""
-    B, D, H, W, n_iter = (4 if a.batch_per_gpu == 64 else a.batch_per_gpu), 32, 160, 608, 12
+    algo3 0 / 2: the persistent kernel (gates resident in registers across all steps: one pass over the 104 B/voxel
+    gate tensor per forward); 1: one step3d_direct_kernel launch per iteration.  -> the result object (rank 0) or None"""
+    D, H, W, n_iter = 32, 160, 608, 12
     gen = torch.Generator(device=dev).manual_seed(5000 + rank)
     g = torch.rand(B, 26, D, H, W, generator=gen, device=dev)
     g /= g.sum(1, keepdim=True)
     h = torch.rand(B, 1, D, H, W, generator=gen, device=dev)
     out = torch.empty_like(h)
     norm = _lib.NORM_TYPES["none"]
-    algo3 = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 2}[a.algo]
     ws_bytes = lib.cspn3d_workspace_bytes_ex(B, D, H, W, n_iter, norm, 0)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -171,27 +201,20 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
         _lib.check(lib.cspn3d_forward_f32_algo(g.data_ptr(), h.data_ptr(), None, out.data_ptr(), B, D, H, W, n_iter, norm, algo3,
                                                ws.data_ptr(), ws_bytes, stream.cuda_stream), "cspn3d_forward_f32_algo")
 
-    steps, warmup = min(a.steps, 60), min(a.warmup, 20)
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
+    if dist is not None:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        warm_now, pre_now = 0, 0.0
+    else:
+        warm_now, pre_now = warmup, prewarm_s
+    elapsed, dev_ms = timed_leg(step, stream, steps, warm_now, pre_now)
     if dist is not None:
         dist.barrier()
-    every = max(1, int(a.event_every))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(steps)]
-    t0 = time.perf_counter()
-    for ev in evs:
-        if ev is not None:
-            ev[0].record(stream)
-        step()
-        if ev is not None:
-            ev[1].record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms_avg = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
-    # parity of what the timed launches left in `out`: the other 3D path on every voxel + the oracle on a sub-volume
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    # parity of what the timed launches left in `out`: the other 3D path on every voxel + the CPU oracle on ONE FULL volume
+    # (volume 1: the chunks of the persistent kernel are cut across the row of volumes, so it has a neighbour on both sides)
     parity = None
     if not a.no_parity_check:
         other = torch.empty_like(out)
@@ -199,98 +222,264 @@ def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
                                                1 if algo3 != 1 else 0, ws.data_ptr(), ws_bytes, stream.cuda_stream), "other 3D path")
         torch.cuda.synchronize()
         err = float((out - other).abs().max() / other.abs().max())
-        parity = {"ok": bool(err <= 1e-5 and torch.isfinite(out).all()), "max_rel_diff_between_3d_paths": err,
+        from oracle import cspn3d_oracle, set_oracle_threads
+        set_oracle_threads(os.cpu_count() or 1)
+        vi = 1 if B > 1 else 0
+        ref = torch.from_numpy(cspn3d_oracle(g[vi:vi + 1].cpu(), h[vi:vi + 1].cpu(), None, n_iter, "none"))
+        got = out[vi:vi + 1].cpu()
+        eo = float((got - ref).abs().max() / ref.abs().max())
+        elem = bool(((got - ref).abs() <= 1e-6 * float(ref.abs().max()) + 1e-4 * ref.abs()).all())
+        del other
+        parity = {"ok": bool(err <= 1e-5 and eo <= 1e-4 and elem and torch.isfinite(out).all()), "max_rel_diff_between_3d_paths": err,
+                  "oracle_full_volume": {"volume": vi, "voxels": D * H * W, "max_rel_err": eo, "rtol": 1e-4},
                   "pinned": False, "note": "the Paddle op's source is not in the reference tree: parity unpinned; the two HIP "
-                  "paths are compared on every voxel, tests/ compare with oracle/ on sub-volumes"}
+                  "paths are compared on every voxel and with oracle/cspn_oracle.c on one full 32x160x608 volume"}
     if dist is not None:
         t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms_avg = float(t[0]), float(t[1])
+    if rank != 0:
+        return None
+    vox = B * D * H * W
+    persistent = algo3 != 1
+    fwd_frac = vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+    traffic, source = pmc_traffic("vol3d_B%d_%s" % (B, "persistent" if persistent else "stepwise"))
+    if persistent:
+        roof = {"bound": "hbm", "kernel": "cspn3d_persistent_kernel (one launch per forward: gates read once, %d steps on chip)" % n_iter,
+                "achieved": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(fwd_frac, 4), "traffic": traffic, "algorithmic_bytes_per_launch": vox * 112,
+                "device_ms_per_launch": round(dev_ms_avg, 4), "device_ms_min": round(dev_ms[0], 4), "whole_forward_frac": round(fwd_frac, 4),
+                "note": "algorithmic bytes = 26 gates + value in, value out = 112 B/voxel ONCE per forward (SURVEY 8d)"}
+    else:
+        launch_ms = dev_ms_avg / n_iter
+        roof = {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
+                "achieved": round(vox * 112 / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(vox * 112 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
+                "whole_forward_frac": round(fwd_frac, 4),
+                "note": "per launch = one propagation step (112 B/voxel); whole_forward_frac prices all %d iterations "
+                        "against a single pass over the inputs" % n_iter}
+    if source:
+        roof["traffic_source"] = source
+    res = {
+        "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
+        "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (uniform gates normalised over the 26 channels, uniform feature volume; generated on device)",
+        "parity_checked": parity,
+        "config": {"workload": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 volume, batch %d per GPU" % B,
+                   "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none (gates pre-normalised by the caller)",
+                   "algo": "persistent" if persistent else "stepwise",
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world},
+        "roofline": roof,
+    }
+    if cpu_base:
+        from oracle import cspn3d_oracle, oracle_threads, set_oracle_threads
+        set_oracle_threads(os.cpu_count() or 1)
+        gc, hc = g[:, :, :, :40].cpu(), h[:, :, :, :40].cpu()   # bounded sample: a 32x40x608 slab of every volume
+        cspn3d_oracle(gc[:1], hc[:1], None, 1, "none")
+        t0 = time.perf_counter()
+        cspn3d_oracle(gc, hc, None, n_iter, "none")
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(gc.shape[0] * D * 40 * W * n_iter / 1e6 / dt, 2), "unit": "Mvox*iters/s",
+                               "cores": oracle_threads(), "kind": "port",
+                               "sample": "%d volumes 32x40x608 x %d iters, oracle/cspn_oracle.c (OpenMP)" % (gc.shape[0], n_iter)}
+    return res
+
+
+def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
+    """--workload vol3d: BASELINE config 5 as the line's workload"""
+    B = 4 if a.batch_per_gpu == 64 else a.batch_per_gpu
+    algo3 = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 2}[a.algo]
+    res = measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, min(a.steps, 60), min(a.warmup, 20), a.prewarm_s,
+                        cpu_base=(world == 1 and not a.no_cpu_baseline))
     if rank == 0:
-        vox = B * D * H * W
-        persistent = algo3 != 1
-        fwd_frac = vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if persistent:
-            roof = {"bound": "hbm", "kernel": "cspn3d_persistent_kernel (one launch per forward: gates read once, %d steps on chip)" % n_iter,
-                    "achieved": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(fwd_frac, 4), "traffic": None, "algorithmic_bytes_per_launch": vox * 112,
-                    "device_ms_per_launch": round(dev_ms_avg, 4), "whole_forward_frac": round(fwd_frac, 4),
-                    "note": "algorithmic bytes = 26 gates + value in, value out = 112 B/voxel ONCE per forward (SURVEY 8d)"}
-        else:
-            launch_ms = dev_ms_avg / n_iter
-            roof = {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
-                    "achieved": round(vox * 112 / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(vox * 112 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
-                    "whole_forward_frac": round(fwd_frac, 4),
-                    "note": "per launch = one propagation step (112 B/voxel); whole_forward_frac prices all %d iterations "
-                            "against a single pass over the inputs" % n_iter}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                t = json.load(open(pmc)).get("vol3d_B%d_%s" % (B, "persistent" if persistent else "stepwise"))
-                if t:
-                    roof["traffic"] = t["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = t.get("source")
-            except Exception:
-                pass
-        res = {
-            "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
-            "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (uniform gates normalised over the 26 channels, uniform feature volume; generated on device)",
-            "parity_checked": parity,
-            "config": {"workload": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 volume, batch %d per GPU" % B,
-                       "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none (gates pre-normalised by the caller)",
-                       "algo": "persistent" if persistent else "stepwise",
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
-            "roofline": roof,
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            from oracle import cspn3d_oracle, oracle_threads, set_oracle_threads
-            set_oracle_threads(min(os.cpu_count() or 1, 64))
-            gc, hc = g[:, :, :, :40].cpu(), h[:, :, :, :40].cpu()   # bounded sample: a 32x40x608 slab of every volume
-            cspn3d_oracle(gc[:1], hc[:1], None, 1, "none")
-            t0 = time.perf_counter()
-            cspn3d_oracle(gc, hc, None, n_iter, "none")
-            dt = time.perf_counter() - t0
-            res["cpu_baseline"] = {"value": round(gc.shape[0] * D * 40 * W * n_iter / 1e6 / dt, 2), "unit": "Mvox*iters/s",
-                                   "cores": oracle_threads(), "kind": "port",
-                                   "sample": "%d volumes 32x40x608 x %d iters, oracle/cspn_oracle.c (OpenMP over volumes)" % (gc.shape[0], n_iter)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch from the PMC passes kept in profiles/pmc_traffic.json (separate rocprofv3 --pmc runs; the file says which
+    profile each entry comes from), or (None, None)"""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(pmc)).get(key)
+        if t:
+            return t["hbm_bytes_per_launch"], t.get("source")
+    except Exception:   # noqa: BLE001
+        pass
+    return None, None
+
+
+def roofline2d(m):
+    """the `roofline` object of one timed 2D forward leg (40 / 44 B per pixel once per forward)"""
+    W, n_iter, algo_name = m["W"], m["n_iter"], m["algo_name"]
+    traffic, source = pmc_traffic("%s_B%d_%s" % (m["workload"], m["B"], algo_name))
+    r = {
+        "bound": "hbm",
+        "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
+                  "stream of its piece of the linear plan in LDS, nothing else runs inside the timed region)"
+                  if algo_name == "fused" and W >= 256 and W % 4 == 0 and n_iter == 24
+                  else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
+                  else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
+        "achieved": round(m["achieved"], 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(m["achieved"] / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": m["alg_bytes"],
+        "device_ms_per_launch": round(m["dev_ms_avg"], 4),
+        "device_ms_min": round(m["dev_ms_min"], 4),
+    }
+    if source:
+        r["traffic_source"] = source
+    return r
+
+
+def timed_leg(step, stream, steps, warmup, prewarm_s):
+    """prewarm (untimed, fixed wall time), `warmup` untimed calls, then `steps` calls each bracketed by a HIP event pair on the
+    launch stream, the whole region bracketed by synchronize.  -> (wall seconds of the timed region, sorted per-call device ms)"""
+    if prewarm_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < prewarm_s:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
+
+def leg_backward2d(lib, _lib, dev, g, h, s, n_iter, norm_name, steps, warmup, prewarm_s):
+    """cspn2d_backward_f32 (what reference cspn_pytorch/train.py:196-198 back-propagates through) on the headline's batch: one call =
+    the recomputing backward (history forward sweep + adjoint sweep + final pass).  Algorithmic bytes of a gradient that touches
+    every tensor once: guidance 32 + blur 4 + grad_out 4 in, grad_guidance 32 + grad_blur 4 out = 76 B/pixel (+ 4 with a mask).
+    Parity: oracle/backward.py (numpy restatement, pinned to gradients of the unmodified reference's autograd) on image 0."""
+    B, _, H, W = g.shape
+    gen = torch.Generator().manual_seed(77)
+    go = torch.randn(B, 1, H, W, generator=gen).to(dev)
+    gg, gh = torch.empty_like(g), torch.empty_like(h)
+    norm = _lib.NORM_TYPES[norm_name]
+    ws_bytes = lib.cspn2d_backward_workspace_bytes(B, H, W, n_iter)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        _lib.check(lib.cspn2d_backward_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, go.data_ptr(),
+                                           gg.data_ptr(), gh.data_ptr(), B, H, W, n_iter, norm, ws.data_ptr(), ws_bytes,
+                                           stream.cuda_stream), "cspn2d_backward_f32")
+
+    elapsed, dev_ms = timed_leg(step, stream, steps, warmup, prewarm_s)
+    ms = sum(dev_ms) / len(dev_ms)
+    from oracle.backward import cspn2d_backward_oracle
+    _, rg, rh = cspn2d_backward_oracle(g[:1].cpu().numpy(), h[:1].cpu().numpy(), None if s is None else s[:1].cpu().numpy(),
+                                       go[:1].cpu().numpy(), n_iter, norm_name)
+    rg, rh = torch.from_numpy(rg), torch.from_numpy(rh)
+    eg = float((gg[:1].cpu() - rg).abs().max() / rg.abs().max())
+    eh = float((gh[:1].cpu() - rh).abs().max() / rh.abs().max())
+    alg = B * H * W * (80 if s is not None else 76)
+    traffic, source = pmc_traffic("backward2d_kitti_B%d" % B)
+    return {
+        "workload": "cspn2d_backward_f32 (gradient of BASELINE config 3's forward w.r.t. guidance and blur_depth), KITTI %dx%d x %d, %d iters"
+                    % (H, W, B, n_iter),
+        "value": round(B * H * W * n_iter * steps / 1e6 / elapsed, 1), "unit": "Mpix*iters/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "parity_checked": {"ok": bool(eg <= 2e-4 and eh <= 2e-4), "images": [0], "max_err_over_max_grad": {"guidance": eg, "blur": eh},
+                           "tol": 2e-4, "against": "oracle/backward.py (pinned to the reference's autograd gradients, tests/golden/cspn2d_grad_golden.npz)"},
+        "roofline": {"bound": "hbm", "kernel": "one cspn2d_backward_f32 call: cspn2d_tsw_kernel history sweep + adjoint sweep + bwd_final_ck_kernel",
+                     "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+                     "algorithmic_bytes_per_launch": alg, "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4),
+                     "note": "per call, not per kernel: three kernels run back to back inside the event pair"},
+    }
+
+
+def extra_configs(a, lib, _lib, dev, headline, notes):
+    """N = 1: the other BASELINE configs and the training path, each timed like the headline (own prewarm, counted warm-up, K steps
+    bracketed by synchronize, per-launch device time from HIP events on the launch stream, parity against the oracle AFTER the
+    timed region), so that the ONE line the driver runs carries a driver-timed roofline fraction for every config."""
+    out = {}
+    steps, warmup = a.steps, a.warmup
+    pre = min(a.prewarm_s, 0.5)
+
+    def fwd2d(key, workload, batch):
+        try:
+            m = measure2d(a, lib, _lib, dev, None, 1, 0, False, "weak", steps, warmup, pre, notes, parity=not a.no_parity_check,
+                          workload=workload, batch=batch)
+            out[key] = {"workload": "%s, batch %d on one GPU" % (m["desc"], m["B"]), "value": round(m["value"], 1), "unit": "Mpix*iters/s",
+                        "steps": steps, "warmup": warmup, "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
+                        "parity_checked": m["parity"], "roofline": roofline2d(m)}
+        except Exception as ex:   # noqa: BLE001 -- a failing leg is reported, it must not cost the headline
+            out[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        torch.cuda.empty_cache()
+
+    # the training path on the headline's own batch (its tensors are still resident)
+    g, h, s = headline["tensors"]
+    try:
+        out["backward2d_kitti_B%d" % g.shape[0]] = leg_backward2d(lib, _lib, dev, g, h, s, headline["n_iter"], a.norm_type, steps, warmup, pre)
+    except Exception as ex:   # noqa: BLE001
+        out["backward2d_kitti_B%d" % g.shape[0]] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    del g, h, s
+    headline["tensors"] = None
+    torch.cuda.empty_cache()
+    fwd2d("config4_kitti_sparse_B32", "kitti_sparse", 32)
+    fwd2d("config2_nyu_B16", "nyu", 16)
+    fwd2d("config3_as_written_share_B8", "kitti", 8)
+    try:
+        out["config5_vol3d_B4"] = measure_vol3d(a, lib, _lib, dev, None, 1, 0, False, 4, 2, min(steps, 60), min(warmup, 20), pre)
+    except Exception as ex:   # noqa: BLE001
+        out["config5_vol3d_B4"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    torch.cuda.empty_cache()
+    return out
+
+
+_COLLECTIVES_BROKEN = [False]   # set by the first failing collective: every later one is skipped (the process group is in an undefined
+                                # state, and a rank that carried on alone would leave the others blocked until the RCCL timeout)
+
+
 def _reduce(dist, vals, op, dev, shared_gpu, notes):
     """all_reduce a few float64 values; a failing collective must not cost the throughput line: rank 0 then reports its own
-    numbers and says so (`notes`)"""
-    if dist is None:
+    numbers, says so (`notes`, "reduced": false), and no further collective is attempted"""
+    if dist is None or _COLLECTIVES_BROKEN[0]:
         return list(vals)
     try:
         t = torch.tensor(list(vals), device="cpu" if shared_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=op)
         return [float(x) for x in t]
     except Exception as ex:   # noqa: BLE001 -- reported, never swallowed silently
-        notes.append("all_reduce failed (%s: %s): rank-0 values reported" % (type(ex).__name__, str(ex)[:200]))
+        _COLLECTIVES_BROKEN[0] = True
+        notes.append("all_reduce failed (%s: %s): rank-0 values reported, later collectives skipped" % (type(ex).__name__, str(ex)[:200]))
         return list(vals)
 
 
 def _barrier(dist, notes):
-    if dist is None:
+    if dist is None or _COLLECTIVES_BROKEN[0]:
         return
     try:
         dist.barrier()
     except Exception as ex:   # noqa: BLE001
-        notes.append("barrier failed (%s: %s)" % (type(ex).__name__, str(ex)[:200]))
+        _COLLECTIVES_BROKEN[0] = True
+        notes.append("barrier failed (%s: %s): later collectives skipped" % (type(ex).__name__, str(ex)[:200]))
 
 
-def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, warmup, prewarm_s, notes, parity=True):
+def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, warmup, prewarm_s, notes, parity=True,
+              workload=None, batch=None, keep_tensors=False):
     """One timed leg of the 2D hot path: `steps` forwards over this rank's batch, bracketed by barrier + synchronize on both sides
     (max over ranks), per-launch device time from HIP events on the launch stream.  scaling 'weak': --batch-per-gpu images on
     every rank; 'strong': --global-batch images sharded (BASELINE config 3 as written)."""
-    H, W, n_iter, sparse, scale, desc = WORKLOADS[a.workload]
+    workload = workload or a.workload
+    H, W, n_iter, sparse, scale, desc = WORKLOADS[workload]
     if scaling == "strong":
         from cspn_amd.dist import shard_range
         first, last = shard_range(a.global_batch, rank, world)
@@ -298,7 +487,8 @@ def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, 
         if B <= 0:
             raise SystemExit("--scaling strong: --global-batch %d leaves rank %d of %d without an image" % (a.global_batch, rank, world))
     else:
-        B, first = a.batch_per_gpu, rank * a.batch_per_gpu
+        B = batch or a.batch_per_gpu
+        first = rank * B
     g, h, s = synth(B, H, W, scale, sparse, dev, first=first)
     algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
     algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
@@ -375,7 +565,8 @@ def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, 
             total_images = a.global_batch
     bytes_per_px = 44 if sparse else 40  # guidance 32 + blur 4 (+ sparse 4) + out 4
     alg_bytes = B * H * W * bytes_per_px  # per launch (one forward = all n_iter iterations), per GPU
-    return {"B": B, "H": H, "W": W, "n_iter": n_iter, "sparse": sparse, "scale": scale, "desc": desc, "algo_name": algo_name,
+    return {"tensors": (g, h, s) if keep_tensors else None, "workload": workload,
+            "B": B, "H": H, "W": W, "n_iter": n_iter, "sparse": sparse, "scale": scale, "desc": desc, "algo_name": algo_name,
             "elapsed": elapsed, "dev_ms_avg": dev_ms_avg, "dev_ms_min": dev_ms[0], "parity": par, "total_images": total_images,
             "value": total_images * H * W * n_iter * steps / 1e6 / elapsed, "alg_bytes": alg_bytes,
             "achieved": alg_bytes / (dev_ms_avg * 1e-3) / 1e9, "prewarm_s": prewarm_done, "prewarm_launches": prewarm_launches}
@@ -435,13 +626,19 @@ def main():
 
     if a.workload == "vol3d":
         return run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu)
+    extras_wanted = (world == 1 and not a.no_extra_configs and a.workload == "kitti" and a.scaling == "weak" and a.layout == "planar"
+                     and not a.plan_mode and a.algo == "auto")
     m = measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, a.scaling, a.steps, a.warmup, a.prewarm_s, notes,
-                  parity=not a.no_parity_check)
+                  parity=not a.no_parity_check, keep_tensors=extras_wanted)
+    # N = 1, the driver's command: after the headline's timed region the other BASELINE configs and the backward, each timed the same way
+    configs = extra_configs(a, lib, _lib, dev, m, notes) if extras_wanted else None
     # N > 1, weak scaling (the driver's command): BASELINE config 3 as written is the STRONG shape (batch 64 sharded over the GPUs),
     # so the same run also times that and reports it under "strong" (same K / W, same barriers, outside the first timed region)
     strong = None
     if world > 1 and a.scaling == "weak" and not a.no_strong_leg:
         try:
+            if _COLLECTIVES_BROKEN[0]:
+                raise SystemExit("a collective failed in the first leg")
             strong = measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, "strong", a.steps, a.warmup, min(a.prewarm_s, 0.3), notes,
                                parity=not a.no_parity_check)
         except SystemExit as ex:
@@ -474,22 +671,7 @@ def main():
                 "parallelism": "batch-sharded x%d, no data-path collective" % world
                                + (" (ranks share %d GPU(s): launch-path test only)" % ndev if shared_gpu else ""),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
-                          "stream of its piece of the linear plan in LDS, nothing else runs inside the timed region)"
-                          if algo_name == "fused" and W >= 256 and W % 4 == 0 and n_iter == 24
-                          else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
-                          else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
-                "achieved": round(m["achieved"], 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(m["achieved"] / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": m["alg_bytes"],
-                "device_ms_per_launch": round(dev_ms_avg, 4),
-                "device_ms_min": round(m["dev_ms_min"], 4),
-            },
+            "roofline": roofline2d(m),
         }
         if world > 1:
             res["backend"] = backend
@@ -505,18 +687,12 @@ def main():
                 "B_per_gpu": strong["B"], "global_batch": strong["total_images"],
                 "roofline_frac_per_gpu": round(strong["achieved"] / HBM_PEAK_GBS, 4), "device_ms_per_launch": round(strong["dev_ms_avg"], 4),
                 "parity_checked": strong["parity"]}
+        if configs is not None:
+            res["configs"] = configs
+        if _COLLECTIVES_BROKEN[0]:
+            res["reduced"] = False   # a collective failed: value / ms_per_step are rank 0's, not the max over ranks
         if notes:
             res["notes"] = notes
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                t = json.load(open(pmc))
-                key = "%s_B%d_%s" % (a.workload, B, algo_name)
-                if key in t:
-                    res["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_source"] = t[key].get("source")
-            except Exception:
-                pass
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W, n_iter, sparse, scale, a.norm_type)
         print(json.dumps(res), flush=True)

@@ -30,8 +30,9 @@ class _CSPN2dFunction(torch.autograd.Function):
         B, _, H, W = guidance.shape
         if (keep_history and needs_grad and algo in ("auto", "fused") and guidance.is_cuda
                 and F.cspn2d_history_bytes(B, H, W, n_iter) > 0):
-            # training: the forward keeps every intermediate level and the folded coefficients (as autograd would keep
-            # the reference's temporaries), the backward starts from them instead of recomputing
+            # training: the forward keeps every FOURTH intermediate level (H_4 .. H_20) and the folded coefficients -- 13 planes,
+            # where autograd keeps ~27 temporaries per iteration for the reference --, the backward starts from them and
+            # recomputes the three levels in between
             out, hist = F.cspn2d_forward_with_history(guidance, blur_depth, sparse_depth, n_iter, norm_type)
             ctx.save_for_backward(guidance, blur_depth, sparse_depth, hist)
             return out

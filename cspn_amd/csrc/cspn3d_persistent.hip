@@ -45,6 +45,7 @@ constexpr int NTP = 64 * XG;                      // 256 registers per thread, 2
 constexpr int LZ = TZ + 2, LY = TY + 2, LXU = TX + 2, LX = TX + 4;   // LDS tile with halo, rows padded to a multiple of 4 floats
 constexpr int LTILE = LZ * LY * LX;              // floats per level buffer
 constexpr unsigned SPIN_MAX = 1u << 18;
+constexpr unsigned CAPTURED_SEQ = 0xffffffffu;   // what a launch captured into a graph stores in the status word (see persistent3d_launch)
 constexpr int MAX_WG = 256 * WG_PER_CU;
 
 struct Geo3 {
@@ -623,7 +624,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // synchronisation at the start of every later 3D call.  (This is the engine's only global mutable state.)
 struct Dev3 {
     int wgs = 0;                      // workgroups that can be resident at once: one per CU (the kernel takes a CU's whole
-    hipEvent_t last = nullptr;        //   register file), at most MAX_WG
+    bool wgs_known = false;           //   register file), at most MAX_WG; 0: the occupancy API says the kernel does not fit
+    hipEvent_t last = nullptr;
     hipStream_t last_stream = nullptr;
     unsigned* status_host = nullptr;  // host-mapped; status_dev is its device address (a kernel argument: Geo3::status)
     unsigned* status_dev = nullptr;
@@ -639,15 +641,30 @@ Dev3& dev3() {
     return g_dev3[dev];
 }
 
+// Pre-flight (round 5): how many workgroups of the persistent kernel the device can hold AT ONCE = CUs x what the occupancy API
+// says one CU takes of each product variant (1 with 512 threads at 256 registers and ~150 KB of LDS; 0 if a variant cannot be
+// launched at all on this device -- then the persistent path is off and AUTO runs the per-step kernels instead of producing NaN).
+// The plan never asks for more workgroups than this (make_geo3), so "n_wg <= occupancy x CUs" holds by construction.  What the
+// API cannot see -- CUs held by ANOTHER process or a CU mask applied behind the runtime's back -- is what the poll timeout and
+// the status word are for.
 int resident_wgs() {
     std::lock_guard<std::mutex> lock(g_mu3);
     Dev3& d = dev3();
-    if (!d.wgs) {
+    if (!d.wgs_known) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
             v = MAX_WG;
-        v *= WG_PER_CU;
+        int occ = WG_PER_CU;
+        const void* fns[] = {(const void*)cspn3d_persistent_kernel<false, false>, (const void*)cspn3d_persistent_kernel<false, true>,
+                             (const void*)cspn3d_persistent_kernel<true, false>, (const void*)cspn3d_persistent_kernel<false, false, false, true>};
+        for (const void* fn : fns) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NTP, 0) == hipSuccess && nb < occ) occ = nb < 0 ? 0 : nb;
+        }
+        (void)hipGetLastError();
+        v *= occ;
         d.wgs = v < MAX_WG ? v : MAX_WG;
+        d.wgs_known = true;
     }
     return d.wgs;
 }
@@ -732,8 +749,19 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     }
     const int mute = opt.mute;
     g.mute = mute;
-    if (++d.seq == 0) d.seq = 1;
-    g.seq = d.seq;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    // the status word receives the NUMBER of the launch that gave up -- except for a launch captured into a graph: its kernel
+    // arguments are frozen at capture time, every replay would store the same number and only the first failing replay would be
+    // reported.  Captured launches therefore store the fixed marker CAPTURED_SEQ, which persistent3d_take_status clears with an
+    // exchange when it reports it: every failing replay is reported (a replay whose other workgroups time out after the report
+    // may be reported twice -- the pre-round-4 behaviour, confined to graphs).
+    if (capturing) {
+        g.seq = CAPTURED_SEQ;
+    } else {
+        if (++d.seq == 0 || d.seq == CAPTURED_SEQ) d.seq = 1;
+        g.seq = d.seq;
+    }
     g.status = d.status_dev;
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
@@ -741,8 +769,6 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
                    : C > 1 ? (const void*)cspn3d_persistent_kernel<false, false, false, true>
                    : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
     const bool coop = opt.coop;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (coop && !capturing) {
         e = hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
     } else if (capturing) {
@@ -775,6 +801,10 @@ int persistent3d_take_status() {
     Dev3& d = dev3();
     if (!d.status_host) return 0;
     const unsigned v = __atomic_load_n(d.status_host, __ATOMIC_RELAXED);
+    if (v == CAPTURED_SEQ) {   // a replayed graph's launch gave up: clear, so that the next failing replay is seen as well
+        __atomic_exchange_n(d.status_host, 0u, __ATOMIC_RELAXED);
+        return 2;
+    }
     if (v == 0 || v == d.reported) return 0;
     d.reported = v;
     return 2;
@@ -793,7 +823,11 @@ int persistent3d_forward_folded(const float* wf, const float* feat, float* out, 
 
 // C value channels per volume on shared gates (feat, out: [B][C][V]; the Paddle contract): one gate load per chunk for all of them
 bool persistent3d_multi_supported(int B, int C, int D, int H, int W, int n_iter) {
-    return C >= 1 && persistent3d_supported(B, D, H, W, n_iter) && (long long)B * C * D * H * W * 4 < (1LL << 32);
+    if (!(C >= 1 && persistent3d_supported(B, D, H, W, n_iter) && (long long)B * C * D * H * W * 4 < (1LL << 32))) return false;
+    // publications are numbered (round * C + channel) * (n_iter - 1) + step in 32 bits: the number must never wrap to a tag the
+    // cleared exchange buffers would validate
+    const Geo3 g = make_geo3(B, D, H, W, n_iter);
+    return (long long)g.nchunk * C * (n_iter - 1) < (1LL << 31);
 }
 
 int persistent3d_forward_multi(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter, void* ws,

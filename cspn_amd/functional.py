@@ -202,6 +202,8 @@ def cspn3d_forward_multi(gate, feat, n_iter=12):
     C = feat.shape[1]
     g = _prep(gate, "gate")
     h = _prep(feat, "feat", (B, C, D, H, W))
+    if h.device != g.device:
+        raise ValueError("all tensors must live on the same device")
     out = torch.empty_like(h)
     if B == 0:
         return out
@@ -288,6 +290,8 @@ def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
         raise ValueError("gate_weight must have %d channels" % (3 ** d - 1))
     N, C = input.shape[:2]
     needs_grad = torch.is_grad_enabled() and (input.requires_grad or gate_weight.requires_grad)
+    if input.device != gate_weight.device:
+        raise ValueError("all tensors must live on the same device")
     if d == 3 and C > 1 and not needs_grad and input.is_cuda and _lib.load().cspn3d_multi_supported(N, C, *input.shape[2:], int(n_iter)) \
             and input.is_contiguous() and gate_weight.is_contiguous() and input.data_ptr() % 16 == 0 and gate_weight.data_ptr() % 16 == 0:
         return cspn3d_forward_multi(gate_weight, input, n_iter)   # the gates are read once for all C channels

@@ -151,18 +151,17 @@ enum { CSPN_ALGO3D_AUTO = 0, CSPN_ALGO3D_STEPWISE = 1, CSPN_ALGO3D_PERSISTENT = 
  * status word.  The NEXT cspn3d_* call of the process on that device (forward or backward, any stream) finds it without a
  * synchronisation, returns CSPN_E_ASYNC instead of enqueuing anything (the reporting call itself is NOT run: call again), and
  * remembers that this launch has been reported: the status word holds the NUMBER of the launch that gave up, so the same
- * launch's other workgroups, which run into their own timeouts later, do not produce a second report.  cspn3d_check_status
- * synchronises `stream` first, so it also reports the call just made: 0, CSPN_E_ASYNC or a hipError_t. */
+ * launch's other workgroups, which run into their own timeouts later, do not produce a second report.  (A launch captured into a
+ * HIP graph replays with frozen arguments: it raises a fixed marker instead, which is cleared when reported, so EVERY failing
+ * replay is reported -- possibly twice, if more of its workgroups time out after the report.)  cspn3d_check_status
+ * synchronises `stream` first, so it also reports the call just made: 0, CSPN_E_ASYNC or a hipError_t.
+ * Pre-flight: the persistent kernel is only chosen when hipOccupancyMaxActiveBlocksPerMultiprocessor x the CU count says all of
+ * its workgroups fit the device at once; otherwise AUTO runs the per-step kernels (and PERSISTENT returns CSPN_E_UNSUPPORTED). */
 int cspn3d_check_status(cspn_stream_t stream);
 int cspn3d_forward_f32_algo(const float* gate, const float* feat, const float* sparse, float* out,
                             int B, int D, int H, int W, int n_iter, int norm_type, int algo,
                             void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
-/* Backward of the 3D op under the Paddle contract (norm_type CSPN_NORM_NONE, no mask): the reference op is differentiated by
- * the demo's optimiser (cspn_paddle/demo.py:65-75, `feat` has stop_gradient=False).  grad_out [B,1,D,H,W];
- * grad_gate [B,26,D,H,W] and grad_feat [B,1,D,H,W] are outputs, either may be NULL.  n_iter chained steps with the same
- * gates are differentiated as one op (n_iter = 1 is the single fluid.layers.affinity_propagate call). */
-size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
 /* C input channels on SHARED gates (reference cspn_paddle/README.md:56: "gate_weight would be shared in the channel dimension for
  * input when C>1"; call site demo.py:41-43): feat, out [B,C,D,H,W], gate [B,26,D,H,W] used as given (norm NONE, no mask), n_iter
  * chained steps.  The gates of a chunk are read ONCE and stay in the registers while the steps run for channel after channel
@@ -173,6 +172,12 @@ size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
 int cspn3d_multi_supported(int B, int C, int D, int H, int W, int n_iter);
 int cspn3d_forward_multi_f32(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter,
                              void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
+/* Backward of the 3D op under the Paddle contract (norm_type CSPN_NORM_NONE, no mask): the reference op is differentiated by
+ * the demo's optimiser (cspn_paddle/demo.py:65-75, `feat` has stop_gradient=False).  grad_out [B,1,D,H,W];
+ * grad_gate [B,26,D,H,W] and grad_feat [B,1,D,H,W] are outputs, either may be NULL.  n_iter chained steps with the same
+ * gates are differentiated as one op (n_iter = 1 is the single fluid.layers.affinity_propagate call). */
+size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
 int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat,
                         int B, int D, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);

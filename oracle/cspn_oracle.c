@@ -165,8 +165,11 @@ int cspn2d_oracle_f32(const float* guidance, const float* blur, const float* spa
  * of channel c is the plane padded by (front=f, top=t, left=l), i.e. neighbour
  * offset (1-f, 1-t, 1-l) -- the same rule that turns cspn.py:105-128's tuples
  * into the eight 2D offsets.                                                  */
+/* par_inner != 0: the voxel loops of THIS volume run on all threads (z-planes in parallel; every voxel's arithmetic and
+ * its order are unchanged, so the result is bit-identical) -- used when there are fewer volumes than threads, so that
+ * one full-size volume (32x160x608) finishes in about a second. */
 static int cspn3d_one(const float* g, const float* feat, const float* sparse, float* out,
-                      int D, int H, int W, int n_iter, int norm_type) {
+                      int D, int H, int W, int n_iter, int norm_type, int par_inner) {
     const int PD = D + 2, PH = H + 2, PW = W + 2;
     const size_t pn = (size_t)PD * PH * PW, n = (size_t)D * H * W;
     int pf[26], pt[26], pl[26], c = 0;
@@ -182,6 +185,7 @@ static int cspn3d_one(const float* g, const float* feat, const float* sparse, fl
     float* res = (float*)malloc(n * sizeof(float));
     if (!w || !gs || !pad || !res) { free(w); free(gs); free(pad); free(res); return -1; }
 
+#pragma omp parallel for collapse(2) schedule(static) if (par_inner)
     for (int z = 0; z < D; ++z)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
@@ -217,6 +221,7 @@ static int cspn3d_one(const float* g, const float* feat, const float* sparse, fl
             for (int y = 0; y < H; ++y)
                 memcpy(pad + ((size_t)(z + 1) * PH + (y + 1)) * PW + 1,
                        res + ((size_t)z * H + y) * W, (size_t)W * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static) if (par_inner)
         for (int z = 0; z < D; ++z)
             for (int y = 0; y < H; ++y)
                 for (int x = 0; x < W; ++x) {
@@ -246,11 +251,13 @@ int cspn3d_oracle_f32(const float* gate, const float* feat, const float* sparse,
     if (B < 0 || D <= 0 || H <= 0 || W <= 0 || n_iter < 0 || norm_type < 0 || norm_type > 2) return -2;
     const size_t n = (size_t)D * H * W;
     int err = 0;
-#pragma omp parallel for schedule(dynamic, 1)
+    /* few volumes: one after the other, each on all threads; many: one thread per volume */
+    const int inner = 2 * B <= omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) if (!inner)
     for (int b = 0; b < B; ++b) {
         int e = cspn3d_one(gate + (size_t)b * 26 * n, feat + (size_t)b * n,
                            sparse ? sparse + (size_t)b * n : NULL, out + (size_t)b * n,
-                           D, H, W, n_iter, norm_type);
+                           D, H, W, n_iter, norm_type, inner);
         if (e) {
 #pragma omp atomic write
             err = e;

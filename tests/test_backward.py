@@ -102,7 +102,8 @@ def test_training_mode_history_matches_recompute_path(norm, sp):
     gg_ref, gh_ref = cspn_amd.cspn2d_backward(gd, hd, sd, go, N, norm)
     out, hist = cspn_amd.cspn2d_forward_with_history(gd, hd, sd, N, norm)
     gg, gh = cspn_amd.cspn2d_backward_from_history(gd, hd, sd, go, hist, N, norm)
-    # (the plain forward runs the round-3 loop, the history forward the round-2 loop: the same arithmetic in another summation order)
+    # (the plain forward streams the pieces of the linear plan, the history forward the band groups: a row lands in another ring
+    # slot, i.e. the same arithmetic in another summation order)
     assert float((out - out_ref).abs().max()) <= 4e-6 * float(out_ref.abs().max())
     assert torch.equal(gg, gg_ref) and torch.equal(gh, gh_ref)
     # through the module: training keeps the history, and the gradients agree with the oracle

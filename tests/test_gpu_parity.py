@@ -310,7 +310,9 @@ def test_3d_persistent_vs_stepwise_and_oracle(B, D, H, W, N):
         assert_close(a.cpu().numpy(), cspn3d_oracle(g.cpu(), h.cpu(), None, N, "none"), "3d persistent")
 
 
-@pytest.mark.parametrize("B,C,D,H,W,N", [(1, 3, 16, 24, 128, 6), (2, 2, 10, 9, 68, 4), (1, 3, 32, 160, 152, 12), (3, 4, 8, 16, 64, 2)])
+@pytest.mark.parametrize("B,C,D,H,W,N", [(1, 3, 16, 24, 128, 6), (2, 2, 10, 9, 68, 4), (1, 3, 32, 160, 152, 12), (3, 4, 8, 16, 64, 2),
+                                         (8, 3, 32, 160, 608, 4)])   # a wide row of volumes: several chunks per launch (the gates of the
+                                                                     # NEXT chunk are parked during channel 0 only)
 def test_3d_shared_gates_multi_channel_equals_per_channel_loop(B, C, D, H, W, N):
     """round 4: C input channels on shared gates (reference cspn_paddle/README.md:56) in ONE persistent launch -- the gates of a chunk
     are loaded once and stay in the registers while the steps run for channel after channel -- against C single-channel calls,
@@ -348,7 +350,12 @@ def test_3d_config5_full_size_persistent_vs_stepwise_every_voxel():
     d = (a - b).abs()
     tol = 1e-6 * float(b.abs().max()) + 1e-5 * b.abs()
     assert bool((d <= tol).all()), float(d.max())
-    del a, b, d, tol
+    # round 5: an INDEPENDENT implementation on a whole volume -- the CPU oracle on all 3.1 M voxels of volume 1 (the chunks are
+    # cut across the row of volumes, so volume 1 sees chunk cuts, a volume seam on both sides and every tile position)
+    ref1 = cspn3d_oracle(g[1:2].cpu(), h[1:2].cpu(), None, N, "none")
+    assert_close(a[1:2].cpu().numpy(), ref1, "3d persistent, full 32x160x608 volume vs the CPU oracle")
+    assert_close(b[1:2].cpu().numpy(), ref1, "3d stepwise, full 32x160x608 volume vs the CPU oracle")
+    del a, b, d, tol, ref1
     sub = (slice(1, 2), slice(None), slice(0, 8), slice(40, 64), slice(544, 608))   # a corner of volume 1 incl. its last columns
     gs, hs = g[sub].contiguous(), h[sub[0], :, sub[2], sub[3], sub[4]].contiguous()
     o = cspn_amd.cspn3d_forward(gs, hs, None, N, "none", algo="persistent")
@@ -460,7 +467,7 @@ def test_sited8_entry_point_vs_oracle(B, H, W, norm, sp):
     planar = cspn_amd.cspn2d_forward(gd, h.to(DEV), None if s is None else s.to(DEV), 24, norm, "fused")
     torch.cuda.synchronize()
     nz = ~torch.isnan(planar)
-    # (the planar entry point runs the round-3 loop since r03, this one the round-2 loop: same arithmetic, another summation order)
+    # (the planar entry point streams the pieces of the linear plan, this one the band groups: same arithmetic, another summation order)
     assert torch.equal(torch.isnan(out), torch.isnan(planar))
     assert float((out[nz] - planar[nz]).abs().max()) <= 4e-6 * float(planar[nz].abs().max())
     if B * H * W <= 200000:

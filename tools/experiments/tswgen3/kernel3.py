@@ -22,7 +22,7 @@ What is new (cspn.py:85-144 normalisation, :76 centre term, :81 mask -- "cooking
     DMA-issuing wave leaves "output byte offset | owned | active" in a per-slot header for the event that injects the row.
 Variants: norm x (sparse | hin | none).  History / adjoint / sparse+hin variants stay on kernel.py's loop.
 """
-from .isa import Prog, V, S, R, EXEC, VCC, M0, I, schedule, check_hazards, expand_pseudos
+from tools.tswgen.isa import Prog, V, S, R, EXEC, VCC, M0, I, schedule, check_hazards, expand_pseudos
 
 R_EXEC_LO, R_EXEC_HI = R("exec", 0, 1), R("exec", 1, 1)
 
@@ -961,7 +961,7 @@ class Gen(object):
 
 
 def build(cfg, sched=True):
-    from . import isa
+    from tools.tswgen import isa
     isa.SOFT_VALU_LATENCY = cfg.get("soft_lat", 1)
     g = Gen(cfg)
     p = g.build()

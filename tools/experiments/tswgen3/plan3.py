@@ -4,7 +4,7 @@ flags (ACTIVE, UP, DN, OWNED) | (image << ybits | y) << 4, ybits = bits needed f
 per-band constant (first column, first / last band, owned columns)."""
 import numpy as np
 
-from . import plan as P2
+from tools.tswgen import plan as P2
 from .kernel3 import PADF, PADB, TAB_MAX_ROWS, F_ACTIVE, F_UP, F_DN, F_OWNED, G_FIRST, G_LAST
 
 BW = 256

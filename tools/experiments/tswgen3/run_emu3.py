@@ -6,10 +6,10 @@ import time
 import numpy as np
 
 from . import kernel3 as K
-from .emu import Emu, EmuError
-from .plan import plan_bands
+from tools.tswgen.emu import Emu, EmuError
+from tools.tswgen.plan import plan_bands
 from .plan3 import build_plan
-from .run_emu import ref_hin
+from tools.tswgen.run_emu import ref_hin
 
 
 def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, cfg=None):

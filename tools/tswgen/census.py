@@ -9,7 +9,7 @@ from . import kernel as K
 def census(cfg):
     cfg = dict(cfg)
     if cfg.pop("loop", 2) == 3:
-        from . import kernel3
+        from tools.experiments.tswgen3 import kernel3
         p = kernel3.build(cfg)
     else:
         p = K.build(cfg)
