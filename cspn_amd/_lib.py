@@ -10,10 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSPN_AMD_LIB") or os.path.join(_HERE, "libcspn_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
+NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2, "prenorm": 3}
 ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 HOOKS_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcspn_amd_hooks.so")
 
@@ -59,12 +59,10 @@ def load():
     lib.cspn2d_forward_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp, c_size_t, vp]
     lib.cspn2d_forward_f32_algo.restype = c_int
     lib.cspn2d_forward_f32_algo.argtypes = [vp, vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
-    lib.cspn2d_sited8_supported.restype = c_int
-    lib.cspn2d_sited8_supported.argtypes = [c_int] * 4
-    lib.cspn2d_guidance_to_sited8_f32.restype = c_int
-    lib.cspn2d_guidance_to_sited8_f32.argtypes = [vp, vp] + [c_int] * 4 + [vp]
-    lib.cspn2d_forward_sited8_f32.restype = c_int
-    lib.cspn2d_forward_sited8_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp]
+    lib.cspn2d_normalize_f32.restype = c_int
+    lib.cspn2d_normalize_f32.argtypes = [vp, vp] + [c_int] * 4 + [vp]
+    lib.cspn2d_forward_prenorm_f32.restype = c_int
+    lib.cspn2d_forward_prenorm_f32.argtypes = [vp, vp, vp, vp] + [c_int] * 4 + [vp, c_size_t, vp]
     lib.cspn2d_backward_workspace_bytes.restype = c_size_t
     lib.cspn2d_backward_workspace_bytes.argtypes = [c_int] * 4
     lib.cspn2d_backward_f32.restype = c_int
@@ -107,6 +105,10 @@ def load():
     lib.cspn3d_multi_supported.argtypes = [c_int] * 6
     lib.cspn3d_forward_multi_f32.restype = c_int
     lib.cspn3d_forward_multi_f32.argtypes = [vp, vp, vp] + [c_int] * 6 + [vp, c_size_t, vp]
+    lib.cspn3d_backward_multi_workspace_bytes.restype = c_size_t
+    lib.cspn3d_backward_multi_workspace_bytes.argtypes = [c_int] * 6
+    lib.cspn3d_backward_multi_f32.restype = c_int
+    lib.cspn3d_backward_multi_f32.argtypes = [vp] * 5 + [c_int] * 6 + [vp, c_size_t, vp]
     lib.cspn3d_check_status.restype = c_int
     lib.cspn3d_check_status.argtypes = [vp]
     _lib = lib
@@ -140,6 +142,12 @@ def load_hooks():
     h.cspn_debug_3d_persistent_forward.argtypes = [vp] * 3 + [c_int] * 7 + [vp, vp]
     h.cspn_debug_3d_backward_stepwise.restype = c_int
     h.cspn_debug_3d_backward_stepwise.argtypes = [vp] * 5 + [c_int] * 5 + [vp, vp]
+    h.cspn_debug_sited8_supported.restype = c_int
+    h.cspn_debug_sited8_supported.argtypes = [c_int] * 4
+    h.cspn_debug_guidance_to_sited8.restype = c_int
+    h.cspn_debug_guidance_to_sited8.argtypes = [vp, vp] + [c_int] * 4 + [vp]
+    h.cspn_debug_forward_sited8.restype = c_int
+    h.cspn_debug_forward_sited8.argtypes = [vp, vp, vp, vp] + [c_int] * 5 + [vp]
     _hooks = h
     return h
 

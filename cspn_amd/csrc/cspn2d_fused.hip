@@ -210,9 +210,10 @@ __device__ __forceinline__ void issue_loads(Pend& p, const RowInfo& ri, int xb, 
     const float* grow = gd + ((size_t)ri.img * 8 + (size_t)(ri.y * g.W));  // channel 0, this row
     const unsigned up = (ri.y + 1 < g.H) ? W4 : 0u;                   // row below / above, clamped into the image
     const unsigned dn = (ri.y >= 1) ? W4 : 0u;
+    constexpr bool GIVEN = NORM == CSPN_NORM_NONE || NORM == CSPN_NORM_PRENORM;   // coefficients used as given, centre-sited
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (NORM == CSPN_NORM_NONE) {
+        if (GIVEN) {
             p.g[k] = ld_row2(grow, oc + (unsigned)k * HW4);
         } else {
             const unsigned chan = (unsigned)k * HW4 + (dy2(k) > 0 ? up : 0u) - (dy2(k) < 0 ? dn : 0u);
@@ -239,11 +240,12 @@ __device__ __forceinline__ void cook_task(const Pend& p, const RowInfo& ri, int 
     const bool el = x0 == 0;                               // pixel 0 has no left neighbour
     const bool er = x0 + 2 == g.W;                         // pixel 1 has no right neighbour
     const bool ru = YINT || ri.y + 1 < g.H, rd = YINT || ri.y >= 1;  // row below / above inside the image
+    constexpr bool GIVEN = NORM == CSPN_NORM_NONE || NORM == CSPN_NORM_PRENORM;
     f2 gv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         f2 t = p.g[k];
-        if (NORM != CSPN_NORM_NONE) {
+        if (!GIVEN) {
             const bool rok = dy2(k) > 0 ? ru : (dy2(k) < 0 ? rd : true);  // wave-uniform
             if (!rok) t = f2{0.f, 0.f};
             if (dx2(k) < 0) t.x = el ? 0.f : t.x;
@@ -255,7 +257,10 @@ __device__ __forceinline__ void cook_task(const Pend& p, const RowInfo& ri, int 
     }
     f2 h0 = p.blur, hv = HIN ? p.hin : p.blur;
     f2 scale = f2{1.f, 1.f}, c = f2{0.f, 0.f};
-    if (NORM != CSPN_NORM_NONE) {
+    if (NORM == CSPN_NORM_PRENORM) {   // the planes are the w_k(p) of cspn.py:138 already: only the centre term is left (cspn.py:76)
+        const f2 T = ((gv[0] + gv[1]) + (gv[2] + gv[3])) + ((gv[4] + gv[5]) + (gv[6] + gv[7]));
+        c = __builtin_elementwise_fma(-T, h0, h0);
+    } else if (!GIVEN) {
         f2 S = f2{0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) S += f2{fabsf(gv[k].x), fabsf(gv[k].y)};
@@ -274,7 +279,7 @@ __device__ __forceinline__ void cook_task(const Pend& p, const RowInfo& ri, int 
     const int cb = q & 7;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const f2 w = (NORM == CSPN_NORM_NONE && !SPARSE) ? gv[k] : gv[k] * scale;
+        const f2 w = (GIVEN && !SPARSE) ? gv[k] : gv[k] * scale;
         lds.cook[cb][k][pos] = w.x;
         lds.cook[cb][k][pos + 2] = w.y;
     }
@@ -601,7 +606,9 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
             case 2: launch_pass<1, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
             case 3: launch_pass<1, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
             case 4: launch_pass<2, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
-            default: launch_pass<2, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 5: launch_pass<2, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            case 6: launch_pass<3, false>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
+            default: launch_pass<3, true>(hd, (int)grid, st, g, blur, hin, sparse, dst, geo); break;
         }
         if (int e = check_launch("cspn2d_fused_kernel")) return e;
         hin = dst;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void fold2d_kernel(const float* __restrict__ g
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float v;
-        if (norm == CSPN_NORM_NONE) {
+        if (norm == CSPN_NORM_NONE || norm == CSPN_NORM_PRENORM) {   // used as given, centre-sited
             v = gb[k * HW + r];
         } else {
             const int yy = y + dy2(k), xx = x + dx2(k);
@@ -39,13 +39,13 @@ __global__ __launch_bounds__(256) void fold2d_kernel(const float* __restrict__ g
     float sigma = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (norm != CSPN_NORM_NONE) G[k] = G[k] / S;  // IEEE: 0/0 -> NaN like torch.div (cspn.py:138)
+        if (norm != CSPN_NORM_NONE && norm != CSPN_NORM_PRENORM) G[k] = G[k] / S;  // IEEE: 0/0 -> NaN like torch.div (cspn.py:138)
         sigma += G[k];
     }
     const float h0 = blur[idx];
     const float m = sparse ? signf(sparse[idx]) : 0.f;
     const float om = 1.f - m;
-    float c = (norm == CSPN_NORM_NONE) ? 0.f : (1.f - sigma) * h0;
+    float c = (norm == CSPN_NORM_NONE) ? 0.f : (1.f - sigma) * h0;   // (PRENORM: the centre term stays, cspn.py:76)
     if (sparse) {
         c = om * c + m * h0;
 #pragma unroll
@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256) void step2d_kernel(const float* __restrict__ w
         acc = fmaf(wf[k * total + idx], hv, acc);
     }
     hout[idx] = acc;
+}
+
+// reference affinity_normalization (cspn.py:85-144) as a stand-alone kernel: wb[B,8,H,W] = gate_wb, i.e. w_k(p) = G_k(p) / sum_j |G_j(p)|
+// with G_k(p) = g~_k(p + off_k), zero outside the image -- what a producer head with a fused epilogue would emit and what
+// norm PRENORM takes (second alternative).  One thread per pixel; 36 B read (L2 serves the shifted re-reads),
+// 32 B written per pixel.
+__global__ __launch_bounds__(256) void normalize2d_kernel(const float* __restrict__ g, float* __restrict__ wb, int B, int H, int W,
+                                                           int norm) {
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = (int)(idx / HW);
+    const int r = (int)(idx - (size_t)b * HW);
+    const int y = r / W, x = r - y * W;
+    const float* gb = g + (size_t)b * 8 * HW;
+    float G[8], S = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int yy = y + dy2(k), xx = x + dx2(k);
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = gb[k * HW + (size_t)yy * W + xx];
+        if (norm == CSPN_NORM_8SUM_ABS) v = fabsf(v);
+        G[k] = v;
+        S += fabsf(v);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wb[((size_t)b * 8 + k) * HW + r] = G[k] / S;   // IEEE division: 0/0 = NaN (cspn.py:138)
+}
+
+int normalize2d(const float* g, float* wb, int B, int H, int W, int norm, hipStream_t st) {
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(normalize2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, wb, B, H, W, norm);
+    return check_launch("normalize2d_kernel");
 }
 
 size_t stepwise2d_workspace(int B, int H, int W, int n_iter) {

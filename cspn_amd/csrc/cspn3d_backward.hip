@@ -50,13 +50,15 @@ struct Pos {
 };
 
 // one adjoint step: aout(q) = sum_k g_k(q - off_k) ain(q - off_k); VEC = 4 (W % 4 == 0, 16-byte aligned tensors) or 1
+// fbs: floats from one volume of ain / aout to the next (V, or C V when the call's C value channels share the gates: the caller
+// passes the channel's first volume)
 template <int VEC>
 __global__ __launch_bounds__(256) void adjoint3d_kernel(const float* __restrict__ g, const float* __restrict__ ain,
-                                                         float* __restrict__ aout, int B, int D, int H, int W) {
+                                                         float* __restrict__ aout, int B, int D, int H, int W, size_t fbs) {
     const Pos<VEC> p(B, D, H, W);
     if (!p.ok) return;
     const size_t HW = (size_t)H * W, V = (size_t)D * HW;
-    const float* ab = ain + (size_t)p.b * V;
+    const float* ab = ain + (size_t)p.b * fbs;
     const float* gb = g + (size_t)p.b * 26 * V;
     float acc[VEC];
 #pragma unroll
@@ -98,29 +100,31 @@ __global__ __launch_bounds__(256) void adjoint3d_kernel(const float* __restrict_
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w[i], a[1 + i - dx], acc[i]);
         }
     }
-    float* o = aout + (size_t)p.b * V + p.r;
+    float* o = aout + (size_t)p.b * fbs + p.r;
     if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     else o[0] = acc[0];
 }
 
-// dL/dg_k(p) = sum_t A_{t+1}(p) H_t(p + off_k).  Level t: H_0 = feat, H_t = hist + (t-1) total; A_n = gout,
-// A_t = ahist + (t-1) total (t = 1 .. n-1)
+// dL/dg_k(p) = sum_c sum_t A^c_{t+1}(p) H^c_t(p + off_k) over the C value channels that share the gates (reference
+// cspn_paddle/README.md:56; C = 1: the plain op).  Every value tensor is [B][C][V]; level t of channel c: H_0 = feat,
+// H_t = hist + (t-1) total; A_n = gout, A_t = ahist + (t-1) total (t = 1 .. n-1), total = B C V
 template <int VEC>
 __global__ __launch_bounds__(256) void gate_grad3d_kernel(const float* __restrict__ feat, const float* __restrict__ hist,
                                                            const float* __restrict__ ahist, const float* __restrict__ gout,
-                                                           float* __restrict__ gg, int B, int D, int H, int W, int n_iter) {
+                                                           float* __restrict__ gg, int B, int D, int H, int W, int n_iter, int C) {
     const Pos<VEC> p(B, D, H, W);
     if (!p.ok) return;
-    const size_t HW = (size_t)H * W, V = (size_t)D * HW, total = (size_t)B * V;
+    const size_t HW = (size_t)H * W, V = (size_t)D * HW, total = (size_t)B * C * V;
     float acc[26][VEC];
 #pragma unroll
     for (int k = 0; k < 26; ++k)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
-    const size_t vox = (size_t)p.b * V + p.r;
 #pragma unroll 1
-    for (int t = 0; t < n_iter; ++t) {
-        const float* ht = (t == 0 ? feat : hist + (size_t)(t - 1) * total) + (size_t)p.b * V;
+    for (int ct = 0; ct < C * n_iter; ++ct) {
+        const int cch = ct / n_iter, t = ct - cch * n_iter;
+        const size_t vol = ((size_t)p.b * C + cch) * V, vox = vol + p.r;
+        const float* ht = (t == 0 ? feat : hist + (size_t)(t - 1) * total) + vol;
         const float* at = t == n_iter - 1 ? gout : ahist + (size_t)t * total;   // A_{t+1}
         float a[VEC];
         if (VEC == 4) {
@@ -168,11 +172,11 @@ __global__ __launch_bounds__(256) void gate_grad3d_kernel(const float* __restric
 
 // forward step for shapes / alignments the 16-byte kernel of cspn3d_stepwise.hip does not take
 __global__ __launch_bounds__(256) void step3d_scalar_kernel(const float* __restrict__ g, const float* __restrict__ hin,
-                                                             float* __restrict__ hout, int B, int D, int H, int W) {
+                                                             float* __restrict__ hout, int B, int D, int H, int W, size_t fbs) {
     const Pos<1> p(B, D, H, W);
     if (!p.ok) return;
     const size_t HW = (size_t)H * W, V = (size_t)D * HW;
-    const float* hb = hin + (size_t)p.b * V;
+    const float* hb = hin + (size_t)p.b * fbs;
     const float* gb = g + (size_t)p.b * 26 * V + p.r;
     float acc = 0.f;
 #pragma unroll
@@ -182,82 +186,91 @@ __global__ __launch_bounds__(256) void step3d_scalar_kernel(const float* __restr
         if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
             acc = fmaf(gb[(size_t)k * V], hb[((size_t)zz * H + yy) * W + xx], acc);
     }
-    hout[(size_t)p.b * V + p.r] = acc;
+    hout[(size_t)p.b * fbs + p.r] = acc;
 }
 
 }  // namespace
 
 // levels kept: H_1 .. H_{n-1} and A_1 .. A_{n-1} (A_0 goes to grad_feat, or to one more volume when the caller does not want
-// it), then the workspace of the persistent kernel (fused sweeps, n >= 3)
-static size_t levels_bytes(int B, int D, int H, int W, int n_iter) {
-    const size_t total = (size_t)B * D * H * W;
+// it), each level B C volumes laid out like feat ([B][C][V]); then the workspace of the persistent kernel (fused sweeps, n >= 3)
+static size_t levels_bytes(int B, int D, int H, int W, int n_iter, int C) {
+    const size_t total = (size_t)B * C * D * H * W;
     const size_t b = (2 * (size_t)(n_iter > 0 ? n_iter - 1 : 0) + 1) * total * sizeof(float);
     return (b + 255) & ~(size_t)255;
 }
 
-size_t backward3d_workspace(int B, int D, int H, int W, int n_iter) {
-    return levels_bytes(B, D, H, W, n_iter) + persistent3d_workspace(B, D, H, W);
+size_t backward3d_workspace(int B, int D, int H, int W, int n_iter, int C) {
+    return levels_bytes(B, D, H, W, n_iter, C) + persistent3d_workspace(B, D, H, W);
 }
 
 int step3d_direct(const float* g, const float* hin, float* hout, int B, int D, int H, int W, hipStream_t st);   // cspn3d_stepwise.hip
 
+// C > 1 (round 5; reference cspn_paddle/README.md:56, trained through at demo.py:65-75): feat / gout / gf hold C value channels per
+// volume on shared gates, gg is the gate gradient summed over the channels.  Fused sweeps: ONE level-keeping forward launch and ONE
+// transposed launch of the persistent kernel for all channels (its MULTI instantiations: the gates of a chunk stay in the registers
+// while the steps run for channel after channel), then one gate-gradient pass that loops over the channels and writes the 26
+// planes once.  Otherwise one launch per step and channel.
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W,
-               int n_iter, void* ws, hipStream_t st, bool stepwise_only) {
-    const size_t total = (size_t)B * D * H * W;
+               int n_iter, void* ws, hipStream_t st, bool stepwise_only, int C) {
+    const size_t V = (size_t)D * H * W, total = (size_t)B * C * V, fbs = (size_t)C * V;
     float* hist = (float*)ws;                                  // H_1 .. H_{n-1}
     float* ahist = hist + (size_t)(n_iter - 1) * total;        // A_1 .. A_{n-1}
     float* a0 = gf ? gf : ahist + (size_t)(n_iter - 1) * total;
     const bool vec = (W % 4) == 0 &&
                      ((((uintptr_t)g | (uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gg | (uintptr_t)gf | (uintptr_t)ws) & 15u) == 0);
-    const unsigned blocks = (unsigned)((total / (vec ? 4 : 1) + 255) / 256);
+    const unsigned blocks = (unsigned)(((size_t)B * V / (vec ? 4 : 1) + 255) / 256);   // threads cover ONE channel's B volumes
     // fused sweeps: the persistent kernel (gates read once per sweep, resident in registers across the steps) in its
     // level-keeping and transposed variants -- forward H_1 .. H_{n-1} (n - 1 steps, the last one "out" = H_{n-1}), adjoint
     // A_{n-1} .. A_0 (n steps).  One launch per step otherwise.
-    void* pws = (char*)ws + levels_bytes(B, D, H, W, n_iter);
-    const bool fused = vec && !stepwise_only && n_iter >= 3 && persistent3d_supported(B, D, H, W, n_iter - 1) &&
-                       persistent3d_supported(B, D, H, W, n_iter);
+    void* pws = (char*)ws + levels_bytes(B, D, H, W, n_iter, C);
+    const bool fused = vec && !stepwise_only && n_iter >= 3 &&
+                       (C == 1 ? persistent3d_supported(B, D, H, W, n_iter - 1) && persistent3d_supported(B, D, H, W, n_iter)
+                               : persistent3d_multi_supported(B, C, D, H, W, n_iter - 1) && persistent3d_multi_supported(B, C, D, H, W, n_iter));
     if (fused) {
         if (gg)
-            if (int e = persistent3d_run(g, feat, hist + (size_t)(n_iter - 2) * total, hist, -1, 1, false, B, D, H, W, n_iter - 1, pws, st))
+            if (int e = persistent3d_run(g, feat, hist + (size_t)(n_iter - 2) * total, hist, -1, 1, false, B, D, H, W, n_iter - 1, pws, st, P3Options(), C))
                 return e;
         // step it of the adjoint run produces A_{n-it}: volume n - it - 1 of ahist; the last one (A_0) is its "out"
         if (gf || gg)
-            if (int e = persistent3d_run(g, gout, a0, ahist, n_iter - 1, -1, true, B, D, H, W, n_iter, pws, st)) return e;
+            if (int e = persistent3d_run(g, gout, a0, ahist, n_iter - 1, -1, true, B, D, H, W, n_iter, pws, st, P3Options(), C)) return e;
         if (gg) {
-            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter, C);
             if (int e = check_launch("gate_grad3d_kernel")) return e;
         }
         return 0;
     }
-    if (gg) {   // the value levels the gate gradient multiplies with
-        const float* src = feat;
-        for (int t = 1; t < n_iter; ++t) {
-            float* dst = hist + (size_t)(t - 1) * total;
-            if (vec) {
-                if (int e = step3d_direct(g, src, dst, B, D, H, W, st)) return e;
-            } else {
-                hipLaunchKernelGGL(step3d_scalar_kernel, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
+    for (int c = 0; c < C; ++c) {
+        const size_t co = (size_t)c * V;
+        if (gg) {   // the value levels the gate gradient multiplies with
+            const float* src = feat + co;
+            for (int t = 1; t < n_iter; ++t) {
+                float* dst = hist + (size_t)(t - 1) * total + co;
+                if (vec && C == 1) {
+                    if (int e = step3d_direct(g, src, dst, B, D, H, W, st)) return e;
+                } else {
+                    hipLaunchKernelGGL(step3d_scalar_kernel, dim3((unsigned)(((size_t)B * V + 255) / 256)), dim3(256), 0, st, g, src, dst, B, D, H, W, fbs);
+                }
+                src = dst;
             }
+            if (int e = check_launch("3D forward levels")) return e;
+        }
+        // adjoint levels A_{n-1} .. A_1 (kept only if the gate gradient needs them: otherwise two volumes would do, but the
+        // workspace is sized for the general call) and A_0
+        const float* src = gout + co;
+        for (int t = n_iter - 1; t >= 0; --t) {
+            float* dst = (t == 0 ? a0 : ahist + (size_t)(t - 1) * total) + co;
+            if (t == 0 && !gf) break;   // A_0 is only the feature gradient
+            if (vec) hipLaunchKernelGGL(adjoint3d_kernel<4>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W, fbs);
+            else hipLaunchKernelGGL(adjoint3d_kernel<1>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W, fbs);
             src = dst;
         }
-        if (int e = check_launch("3D forward levels")) return e;
+        if (int e = check_launch("adjoint3d_kernel")) return e;
     }
-    // adjoint levels A_{n-1} .. A_1 (kept only if the gate gradient needs them: otherwise two volumes would do, but the
-    // workspace is sized for the general call) and A_0
-    const float* src = gout;
-    for (int t = n_iter - 1; t >= 0; --t) {
-        float* dst = t == 0 ? a0 : ahist + (size_t)(t - 1) * total;
-        if (t == 0 && !gf) break;   // A_0 is only the feature gradient
-        if (vec) hipLaunchKernelGGL(adjoint3d_kernel<4>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
-        else hipLaunchKernelGGL(adjoint3d_kernel<1>, dim3(blocks), dim3(256), 0, st, g, src, dst, B, D, H, W);
-        src = dst;
-    }
-    if (int e = check_launch("adjoint3d_kernel")) return e;
     if (gg) {
         if (vec)
-            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+            hipLaunchKernelGGL(gate_grad3d_kernel<4>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter, C);
         else
-            hipLaunchKernelGGL(gate_grad3d_kernel<1>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter);
+            hipLaunchKernelGGL(gate_grad3d_kernel<1>, dim3(blocks), dim3(256), 0, st, feat, hist, ahist, gout, gg, B, D, H, W, n_iter, C);
         if (int e = check_launch("gate_grad3d_kernel")) return e;
     }
     return 0;

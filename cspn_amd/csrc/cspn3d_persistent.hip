@@ -484,7 +484,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) own[i] = acc[i];
-                    if (levels) store_owned(levels + (size_t)(g.lv0 + it * g.lvs) * total);   // the level history of the backward
+                    // the level history of the backward (MULTI: volumes laid out [level][B][C][V], like feat / out)
+                    if (levels) store_owned(levels + (size_t)(g.lv0 + it * g.lvs) * (MULTI ? total * (size_t)g.C : total) + (MULTI ? (size_t)ch * V : 0));
                     P3_STAMP(1);
                     // publications are numbered through the whole launch and alternate between the two buffers, so the
                     // one overwritten was consumed by every neighbour (they published the step in between) and chunks need no barrier
@@ -656,7 +657,8 @@ int resident_wgs() {
             v = MAX_WG;
         int occ = WG_PER_CU;
         const void* fns[] = {(const void*)cspn3d_persistent_kernel<false, false>, (const void*)cspn3d_persistent_kernel<false, true>,
-                             (const void*)cspn3d_persistent_kernel<true, false>, (const void*)cspn3d_persistent_kernel<false, false, false, true>};
+                             (const void*)cspn3d_persistent_kernel<true, false>, (const void*)cspn3d_persistent_kernel<false, false, false, true>,
+                             (const void*)cspn3d_persistent_kernel<true, false, false, true>};
         for (const void* fn : fns) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NTP, 0) == hipSuccess && nb < occ) occ = nb < 0 ? 0 : nb;
@@ -765,7 +767,7 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
     g.status = d.status_dev;
     void* args[] = {(void*)&gate, (void*)&feat, (void*)&cprime, (void*)&out, (void*)&levels, (void*)&scratch, (void*)&sync, (void*)&g};
     const void* fn = cprime ? (const void*)cspn3d_persistent_kernel<false, true>
-                   : adjoint ? (const void*)cspn3d_persistent_kernel<true, false>
+                   : adjoint ? (C > 1 ? (const void*)cspn3d_persistent_kernel<true, false, false, true> : (const void*)cspn3d_persistent_kernel<true, false>)
                    : C > 1 ? (const void*)cspn3d_persistent_kernel<false, false, false, true>
                    : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
     const bool coop = opt.coop;
@@ -811,8 +813,8 @@ int persistent3d_take_status() {
 }
 
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
-                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt) {
-    return persistent3d_launch(gate, feat, nullptr, out, levels, lv0, lvs, adjoint, B, D, H, W, n_iter, ws, st, opt);
+                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt, int C) {
+    return persistent3d_launch(gate, feat, nullptr, out, levels, lv0, lvs, adjoint, B, D, H, W, n_iter, ws, st, opt, C);
 }
 
 // H_{t+1} = c' + sum_k w'_k H_t(p + off_k) with the folded planes wf = [26 w'][c'] of fold3d_kernel

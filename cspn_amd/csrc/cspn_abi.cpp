@@ -42,10 +42,11 @@ int num_cus() {
 }
 
 static int check_common(const void* a, const void* b, const void* out, int n_iter, int norm, const void* ws,
-                        size_t ws_bytes, size_t need) {
+                        size_t ws_bytes, size_t need, int norm_max = CSPN_NORM_NONE) {
     if (!a || !b || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
     if (n_iter < 0) { set_error("n_iter must be >= 0 (got %d)", n_iter); return CSPN_E_BADARG; }
-    if (norm < CSPN_NORM_8SUM || norm > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm); return CSPN_E_BADARG; }
+    if (norm < CSPN_NORM_8SUM || norm > CSPN_NORM_PRENORM) { set_error("unknown norm_type %d", norm); return CSPN_E_BADARG; }
+    if (norm > norm_max) { set_error("norm_type CSPN_NORM_PRENORM is taken by the 2D forward only"); return CSPN_E_UNSUPPORTED; }
     if (need && (!ws || ws_bytes < need)) {
         set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return CSPN_E_WORKSPACE;
@@ -91,7 +92,7 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
     size_t need = n_iter == 0 ? 0
                   : (fused ? fused2d_workspace(B, H, W, n_iter)
                                              : stepwise2d_workspace(B, H, W, n_iter));
-    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, need)) return e;
+    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, need, CSPN_NORM_PRENORM)) return e;
     if (n_iter == 0) {  // reference cspn.py:61,66,83: the loop body never runs
         hipError_t e = hipMemcpyAsync(out, blur, sizeof(float) * (size_t)B * H * W, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
@@ -107,43 +108,17 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
                                    ws_bytes, stream);
 }
 
-// ---- SURVEY 8f-2 experiment: guidance as 32 contiguous bytes per pixel, pre-sited by the producer
-// Measured 9 % slower than the planar contract and closed: the loop variants are only in experiment builds
-// (make -C cspn_amd/csrc EXPERIMENTS=1); the default library answers "unsupported".
-#ifdef CSPN_EXPERIMENTS
-int cspn2d_sited8_supported(int B, int H, int W, int n_iter) { return n_iter == 24 && tsw2d_supported(B, H, W) ? 1 : 0; }   // (W >= 256, W % 4 == 0)
-#else
-int cspn2d_sited8_supported(int, int, int, int) { return 0; }
-#endif
-
-int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type, cspn_stream_t stream) {
-    if (!guidance || !guidance_s8 || B <= 0 || H <= 0 || W <= 0 || (W % 2) != 0) { set_error("bad argument (W must be even)"); return CSPN_E_BADARG; }
-    if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
-    if (((uintptr_t)guidance_s8 & 15u) != 0) { set_error("guidance_s8 must be 16-byte aligned"); return CSPN_E_BADARG; }
-#ifdef CSPN_EXPERIMENTS
-    return guidance_to_sited8(guidance, guidance_s8, B, H, W, norm_type, (hipStream_t)stream);
-#else
-    (void)stream;
-    set_error("the sited8 experiment is not part of this build (make EXPERIMENTS=1)");
-    return CSPN_E_UNSUPPORTED;
-#endif
+// ---- SURVEY 8f-2, second alternative: the normalisation done by the producer of the guidance (include/cspn_amd.h) ----
+int cspn2d_normalize_f32(const float* guidance, float* wb, int B, int H, int W, int norm_type, cspn_stream_t stream) {
+    if (!guidance || !wb || B <= 0 || H <= 0 || W <= 0) { set_error("bad argument"); return CSPN_E_BADARG; }
+    if (norm_type != CSPN_NORM_8SUM && norm_type != CSPN_NORM_8SUM_ABS) { set_error("cspn2d_normalize_f32: norm_type must be 8SUM or 8SUM_ABS (got %d)", norm_type); return CSPN_E_BADARG; }
+    if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
+    return normalize2d(guidance, wb, B, H, W, norm_type, (hipStream_t)stream);
 }
 
-int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const float* sparse, float* out, int B, int H, int W,
-                              int n_iter, int norm_type, cspn_stream_t stream) {
-    if (!guidance_s8 || !blur || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
-    if (norm_type < CSPN_NORM_8SUM || norm_type > CSPN_NORM_NONE) { set_error("unknown norm_type %d", norm_type); return CSPN_E_BADARG; }
-    if (!cspn2d_sited8_supported(B, H, W, n_iter)) {
-        set_error("the sited8 entry point (experiment builds only) takes passes of exactly 24 iterations on images >= 256 columns wide, W %% 4 == 0");
-        return CSPN_E_UNSUPPORTED;
-    }
-#ifdef CSPN_EXPERIMENTS
-    if ((((uintptr_t)guidance_s8 | (uintptr_t)out) & 15u) != 0) { set_error("guidance_s8 and out must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
-    return tsw2d_pass_sited8(guidance_s8, blur, sparse, out, B, H, W, norm_type, (hipStream_t)stream);
-#else
-    (void)sparse; (void)stream;
-    return CSPN_E_UNSUPPORTED;
-#endif
+int cspn2d_forward_prenorm_f32(const float* wb, const float* blur, const float* sparse, float* out, int B, int H, int W, int n_iter,
+                               void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    return cspn2d_forward_f32_algo(wb, blur, sparse, out, B, H, W, n_iter, CSPN_NORM_PRENORM, CSPN_ALGO_AUTO, ws, ws_bytes, stream);
 }
 
 size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter) {
@@ -300,6 +275,33 @@ int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_
         return 0;
     }
     return backward3d(gate, feat, grad_out, grad_gate, grad_feat, B, D, H, W, n_iter, ws, st);
+}
+
+size_t cspn3d_backward_multi_workspace_bytes(int B, int C, int D, int H, int W, int n_iter) {
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
+    return backward3d_workspace(B, D, H, W, n_iter, C);
+}
+
+int cspn3d_backward_multi_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat, int B,
+                              int C, int D, int H, int W, int n_iter, void* ws, size_t ws_bytes, cspn_stream_t stream) {
+    if (B < 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) { set_error("bad shape B=%d C=%d D=%d H=%d W=%d", B, C, D, H, W); return CSPN_E_BADARG; }
+    if (B == 0) return 0;
+    if ((long long)B * D * H * W > 0x7fffffffLL / 27 || (long long)B * C * D * H * W > 0x7fffffffLL / 2) {
+        set_error("tensor too large for 32-bit plane indexing");
+        return CSPN_E_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = async_failure_of_earlier_call()) return e;
+    if (int e = check_common(gate, feat, grad_out, n_iter, CSPN_NORM_NONE, ws, ws_bytes, n_iter == 0 ? 0 : backward3d_workspace(B, D, H, W, n_iter, C))) return e;
+    if (!grad_gate && !grad_feat) return 0;
+    if (n_iter == 0) {   // identity: dL/dfeat = dL/dout, the gates are not used
+        hipError_t e = hipSuccess;
+        if (grad_feat) e = hipMemcpyAsync(grad_feat, grad_out, sizeof(float) * (size_t)B * C * D * H * W, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && grad_gate) e = hipMemsetAsync(grad_gate, 0, 26 * sizeof(float) * (size_t)B * D * H * W, st);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync / hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+    }
+    return backward3d(gate, feat, grad_out, grad_gate, grad_feat, B, D, H, W, n_iter, ws, st, false, C);
 }
 
 }  // extern "C"

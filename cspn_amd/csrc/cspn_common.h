@@ -31,6 +31,8 @@ int num_cus();
 size_t stepwise2d_workspace(int B, int H, int W, int n_iter);
 int stepwise2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
                        int n_iter, int norm, void* ws, hipStream_t st);
+// reference affinity_normalization (cspn.py:85-144) as a stand-alone kernel: g [B,8,H,W] -> gate_wb [B,8,H,W] (norm 8SUM / 8SUM_ABS)
+int normalize2d(const float* g, float* wb, int B, int H, int W, int norm, hipStream_t st);
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter);
 int stepwise3d_forward(const float* g, const float* feat, const float* sparse, float* out, int B, int D, int H,
                        int W, int n_iter, int norm, void* ws, hipStream_t st, int algo = 0);
@@ -48,8 +50,9 @@ int persistent3d_forward_folded(const float* wf, const float* feat, float* out, 
 // boundary (its neighbours then run into the poll timeout), coop = hipLaunchCooperativeKernel instead of the event chain
 struct P3Options { int mute = -1; bool coop = false; };
 // the same run for the backward: adjoint = transposed operator; levels + (lv0 + it * lvs) volumes receive step it < n_iter
+// C > 1: feat / out / the level volumes hold C value channels per volume ([B][C][V]) on shared gates (the MULTI instantiations)
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
-                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt = P3Options());
+                     int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt = P3Options(), int C = 1);
 int persistent3d_error_word(const void* ws, int B, int D, int H, int W);
 // C value channels per volume that share the gates ([B][C][V] value tensors, [B][26][V] gates used as given)
 bool persistent3d_multi_supported(int B, int C, int D, int H, int W, int n_iter);
@@ -61,9 +64,10 @@ int persistent3d_forward_multi(const float* gate, const float* feat, float* out,
 int persistent3d_take_status();
 
 // ---- backward of the 3D op, Paddle contract only (cspn3d_backward.hip) ----
-size_t backward3d_workspace(int B, int D, int H, int W, int n_iter);
+// C > 1: feat / gout / gf are [B][C][V] on shared gates; gg [B][26][V] is the sum over the channels
+size_t backward3d_workspace(int B, int D, int H, int W, int n_iter, int C = 1);
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W, int n_iter,
-               void* ws, hipStream_t st, bool stepwise_only = false /* test-hook library: one launch per step */);
+               void* ws, hipStream_t st, bool stepwise_only = false /* test-hook library: one launch per step */, int C = 1);
 
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);

@@ -86,4 +86,39 @@ int cspn_debug_3d_backward_stepwise(const float* gate, const float* feat, const 
     return backward3d(gate, feat, gout, gg, gf, B, D, H, W, n_iter, ws, (hipStream_t)stream, true);
 }
 
+// ---- SURVEY 8f-2, FIRST alternative (closed experiment; experiment builds only: make EXPERIMENTS=1): the guidance as
+// 32 contiguous bytes per pixel pair record, gathered by the producer -- [B][H][W/2][8][2] floats, record of the pixel pair
+// (x, x+1) = (G_0(x), G_0(x+1), G_1(x), ...), G_k(p) = g_k(p + off_k), zero outside the image.  Measured 9 % slower than the planar
+// contract; these three were part of the ABI until round 4.
+int cspn_debug_sited8_supported(int B, int H, int W, int n_iter) {
+#ifdef CSPN_EXPERIMENTS
+    return n_iter == 24 && tsw2d_supported(B, H, W) ? 1 : 0;   // (W >= 256, W % 4 == 0)
+#else
+    (void)B; (void)H; (void)W; (void)n_iter;
+    return 0;
+#endif
+}
+
+int cspn_debug_guidance_to_sited8(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type, void* stream) {
+#ifdef CSPN_EXPERIMENTS
+    if (!guidance || !guidance_s8 || B <= 0 || H <= 0 || W <= 0 || (W % 2) != 0 || ((uintptr_t)guidance_s8 & 15u) != 0) return CSPN_E_BADARG;
+    return guidance_to_sited8(guidance, guidance_s8, B, H, W, norm_type, (hipStream_t)stream);
+#else
+    (void)guidance; (void)guidance_s8; (void)B; (void)H; (void)W; (void)norm_type; (void)stream;
+    return CSPN_E_UNSUPPORTED;
+#endif
+}
+
+int cspn_debug_forward_sited8(const float* guidance_s8, const float* blur, const float* sparse, float* out, int B, int H, int W,
+                              int n_iter, int norm_type, void* stream) {
+#ifdef CSPN_EXPERIMENTS
+    if (!guidance_s8 || !blur || !out) return CSPN_E_BADARG;
+    if (!cspn_debug_sited8_supported(B, H, W, n_iter) || (((uintptr_t)guidance_s8 | (uintptr_t)out) & 15u) != 0) return CSPN_E_UNSUPPORTED;
+    return tsw2d_pass_sited8(guidance_s8, blur, sparse, out, B, H, W, norm_type, (hipStream_t)stream);
+#else
+    (void)guidance_s8; (void)blur; (void)sparse; (void)out; (void)B; (void)H; (void)W; (void)n_iter; (void)norm_type; (void)stream;
+    return CSPN_E_UNSUPPORTED;
+#endif
+}
+
 }  // extern "C"

@@ -52,23 +52,44 @@ def cspn2d_forward(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type
     return out
 
 
-def guidance_to_sited8(guidance, norm_type="8sum"):
-    """[B,8,H,W] -> the producer-side layout [B,H,W/2,8,2] of include/cspn_amd.h (SURVEY 8f-2 experiment): what a
-    fused conv epilogue would emit; here a stand-alone kernel."""
+def cspn2d_normalize(guidance, norm_type="8sum"):
+    """reference affinity_normalization (cspn_pytorch/models/cspn.py:85-144) as a stand-alone HIP kernel: guidance [B,8,H,W] ->
+    gate_wb [B,8,H,W] (normalised, consumer-sited): what a producer head with a fused epilogue would emit, and what
+    cspn2d_forward(..., norm_type="prenorm") takes in place of the raw guidance."""
     lib = _lib.load()
+    if guidance.dim() != 4 or guidance.shape[1] != 8:
+        raise ValueError("guidance must be [B,8,H,W], got %s" % (tuple(guidance.shape),))
+    g = _prep(guidance, "guidance")
+    B, _, H, W = g.shape
+    out = torch.empty_like(g)
+    if B == 0:
+        return out
+    with torch.cuda.device(g.device):
+        rc = lib.cspn2d_normalize_f32(g.data_ptr(), out.data_ptr(), B, H, W, _lib.NORM_TYPES[norm_type],
+                                      torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn2d_normalize_f32")
+    return out
+
+
+def guidance_to_sited8(guidance, norm_type="8sum"):
+    """(closed experiment, experiment builds only: libcspn_amd_hooks.so) [B,8,H,W] -> the pre-sited pair-interleaved layout
+    [B,H,W/2,8,2] of DESIGN.md 3.6"""
+    hooks = _lib.load_hooks()
     g = _prep(guidance, "guidance")
     B, _, H, W = g.shape
     out = torch.empty(B, H, W // 2, 8, 2, dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        rc = lib.cspn2d_guidance_to_sited8_f32(g.data_ptr(), out.data_ptr(), B, H, W, _lib.NORM_TYPES[norm_type],
-                                               torch.cuda.current_stream(g.device).cuda_stream)
-    _lib.check(rc, "cspn2d_guidance_to_sited8_f32")
+        rc = hooks.cspn_debug_guidance_to_sited8(g.data_ptr(), out.data_ptr(), B, H, W, _lib.NORM_TYPES[norm_type],
+                                                 torch.cuda.current_stream(g.device).cuda_stream)
+    if rc != 0:
+        raise _lib.CspnError("cspn_debug_guidance_to_sited8 failed (code %d): the sited8 experiment is only in experiment builds "
+                             "(make -C cspn_amd/csrc EXPERIMENTS=1)" % rc)
     return out
 
 
 def cspn2d_forward_sited8(guidance_s8, blur_depth, sparse_depth=None, n_iter=24, norm_type="8sum"):
-    """cspn2d_forward with the guidance already in the producer-side layout (24 iterations, W >= 256 only)."""
-    lib = _lib.load()
+    """(closed experiment, experiment builds only) cspn2d_forward with the guidance in the sited8 layout (24 iterations, W >= 256)."""
+    hooks = _lib.load_hooks()
     B, H, W2 = guidance_s8.shape[:3]
     W = 2 * W2
     g = _prep(guidance_s8, "guidance_s8", (B, H, W2, 8, 2))
@@ -76,10 +97,12 @@ def cspn2d_forward_sited8(guidance_s8, blur_depth, sparse_depth=None, n_iter=24,
     s = _prep(sparse_depth, "sparse_depth", (B, 1, H, W)) if sparse_depth is not None else None
     out = torch.empty_like(h)
     with torch.cuda.device(g.device):
-        rc = lib.cspn2d_forward_sited8_f32(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
-                                           B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
-                                           torch.cuda.current_stream(g.device).cuda_stream)
-    _lib.check(rc, "cspn2d_forward_sited8_f32")
+        rc = hooks.cspn_debug_forward_sited8(g.data_ptr(), h.data_ptr(), s.data_ptr() if s is not None else None, out.data_ptr(),
+                                             B, H, W, int(n_iter), _lib.NORM_TYPES[norm_type],
+                                             torch.cuda.current_stream(g.device).cuda_stream)
+    if rc != 0:
+        raise _lib.CspnError("cspn_debug_forward_sited8 failed (code %d): experiment builds only, passes of exactly 24 iterations, "
+                             "W >= 256, W %% 4 == 0" % rc)
     return out
 
 
@@ -253,6 +276,53 @@ def cspn3d_backward(gate, feat, grad_out, n_iter=1, need_gate=True, need_feat=Tr
     return gg, gf
 
 
+def cspn3d_backward_multi(gate, feat, grad_out, n_iter=1, need_gate=True, need_feat=True):
+    """Gradient of the n_iter-step 3D propagation of C channels on SHARED gates (feat, grad_out [B,C,D,H,W]; reference
+    cspn_paddle/README.md:56, differentiated at demo.py:65-75) -> (grad_gate [B,26,D,H,W] summed over the channels or None,
+    grad_feat [B,C,D,H,W] or None); one call of the HIP engine (cspn3d_backward_multi_f32)."""
+    lib = _lib.load()
+    if gate.dim() != 5 or gate.shape[1] != 26:
+        raise ValueError("gate must be [B,26,D,H,W], got %s" % (tuple(gate.shape),))
+    B, _, D, H, W = gate.shape
+    C = feat.shape[1]
+    g = _prep(gate, "gate")
+    h = _prep(feat, "feat", (B, C, D, H, W))
+    go = _prep(grad_out, "grad_out", (B, C, D, H, W))
+    if h.device != g.device or go.device != g.device:
+        raise ValueError("all tensors must live on the same device")
+    gg = torch.empty_like(g) if need_gate else None
+    gf = torch.empty_like(h) if need_feat else None
+    if B == 0 or not (need_gate or need_feat):
+        return gg, gf
+    with torch.cuda.device(g.device):
+        ws_bytes = lib.cspn3d_backward_multi_workspace_bytes(B, C, D, H, W, int(n_iter))
+        ws = _workspace(ws_bytes, g.device)
+        rc = lib.cspn3d_backward_multi_f32(g.data_ptr(), h.data_ptr(), go.data_ptr(), gg.data_ptr() if gg is not None else None,
+                                           gf.data_ptr() if gf is not None else None, B, C, D, H, W, int(n_iter),
+                                           ws.data_ptr(), ws_bytes, torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "cspn3d_backward_multi_f32")
+    return gg, gf
+
+
+class _AffinityPropagateMultiFunction(torch.autograd.Function):
+    """3D, C > 1 input channels on shared gates: forward and backward are one engine call each for all channels"""
+
+    @staticmethod
+    def forward(ctx, x, gate_weight, n_iter):
+        ctx.n_iter = int(n_iter)
+        ctx.save_for_backward(x, gate_weight)
+        if _lib.load().cspn3d_multi_supported(x.shape[0], x.shape[1], *x.shape[2:], int(n_iter)) and x.data_ptr() % 16 == 0 \
+                and gate_weight.data_ptr() % 16 == 0:
+            return cspn3d_forward_multi(gate_weight, x, n_iter)
+        return torch.cat([cspn3d_forward(gate_weight, x[:, c:c + 1].contiguous(), None, n_iter, "none") for c in range(x.shape[1])], 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, gate_weight = ctx.saved_tensors
+        gg, gx = cspn3d_backward_multi(gate_weight, x, grad_out, ctx.n_iter, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        return gx, gg, None
+
+
 class _AffinityPropagateFunction(torch.autograd.Function):
     """n_iter chained propagation steps with the same gates, one input channel; differentiable w.r.t. both arguments."""
 
@@ -295,6 +365,9 @@ def affinity_propagate(input, gate_weight, kernel_size=3, n_iter=1):
     if d == 3 and C > 1 and not needs_grad and input.is_cuda and _lib.load().cspn3d_multi_supported(N, C, *input.shape[2:], int(n_iter)) \
             and input.is_contiguous() and gate_weight.is_contiguous() and input.data_ptr() % 16 == 0 and gate_weight.data_ptr() % 16 == 0:
         return cspn3d_forward_multi(gate_weight, input, n_iter)   # the gates are read once for all C channels
+    if d == 3 and C > 1 and needs_grad and input.is_cuda:
+        # training through C channels on shared gates (demo.py:65-75): one forward and one backward call for all of them
+        return _AffinityPropagateMultiFunction.apply(input.contiguous(), gate_weight.contiguous(), n_iter)
     outs = []
     for c in range(C):  # gates shared across channels (README.md:56)
         x = input[:, c:c + 1].contiguous()

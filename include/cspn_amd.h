@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 3   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32 */
+#define CSPN_ABI_VERSION 4   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32;
+                              * 4: CSPN_NORM_PRENORM, cspn2d_normalize_f32, cspn2d_forward_prenorm_f32, cspn3d_backward_multi_f32; the
+                              *    sited8 experiment's three entry points left the ABI (hook library, experiment builds) */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -49,7 +51,8 @@ typedef void* cspn_stream_t;
  * NONE = gates are used as given, centre-sited, no centre term -- the contract of
  * fluid.layers.affinity_propagate (reference cspn_paddle/README.md:54: "should be
  * normalized in the channel dimension" by the caller, cspn_paddle/demo.py:47-49). */
-enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2 };
+enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2,
+       CSPN_NORM_PRENORM = 3 /* 2D forward only: `guidance` holds the reference's gate_wb (see cspn2d_normalize_f32 below) */ };
 
 /* algo: AUTO picks the fused single-launch kernel whenever the shape allows it.  FUSED runs every pass of exactly 24
  * iterations through the assembly main loop when the image is at least 256 columns wide; FUSED_CXX forces the
@@ -85,21 +88,20 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
 /* which kernel AUTO would run for this shape: CSPN_ALGO_STEPWISE or CSPN_ALGO_FUSED */
 int cspn2d_auto_algo(int B, int H, int W, int n_iter);
 
-/* ---- 2D with the guidance in a producer-side layout (an ADDITIONAL entry point, the contract above is
- * unchanged).  guidance_s8 = [B][H][W/2][8][2] floats: the record of the pixel pair (x, x+1), x even, holds
- * (G_0(x), G_0(x+1), G_1(x), ..., G_7(x+1)) with G_k(p) = g_k(p + off_k), zero outside the image -- the gather of
- * reference cspn.py:91-132 done by whoever writes the guidance (its natural home is the epilogue of the conv at
- * cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206,372); norm NONE: the centre-sited g_k(p).
- * cspn2d_guidance_to_sited8_f32 is that epilogue as a stand-alone kernel (tests, A/B timing).  Only where
- * cspn2d_sited8_supported(...) != 0 (passes of exactly 24 iterations, W >= 256, W % 4 == 0); no workspace.
- * (SURVEY 8f-2 was measured with this entry point and closed: 9 % slower than the planar contract, DESIGN.md 3.6.  Round 4:
- * its loop variants are only in experiment builds -- make -C cspn_amd/csrc EXPERIMENTS=1 --; in the default library
- * cspn2d_sited8_supported() is 0 for every shape and the other two entry points return CSPN_E_UNSUPPORTED.) */
-int cspn2d_sited8_supported(int B, int H, int W, int n_iter);
-int cspn2d_guidance_to_sited8_f32(const float* guidance, float* guidance_s8, int B, int H, int W, int norm_type,
-                                  cspn_stream_t stream);
-int cspn2d_forward_sited8_f32(const float* guidance_s8, const float* blur, const float* sparse, float* out,
-                              int B, int H, int W, int n_iter, int norm_type, cspn_stream_t stream);
+/* ---- 2D with the normalisation moved to the producer (second alternative: "fuse normalisation into that conv's
+ * epilogue", the conv being gud_up_proj_layer6 at cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206,318-319,372-373).
+ * The contract is the reference's own intermediate: `gate_wb`, what affinity_normalization returns (cspn.py:85-144, used at
+ * :69-76) -- wb [B,8,H,W] with wb_k(p) = G_k(p) / sum_j |G_j(p)|, G_k(p) = g~_k(p + off_k), zero outside the image: normalised AND
+ * consumer-sited, the same 32 B/pixel as the raw guidance.  norm_type CSPN_NORM_PRENORM on cspn2d_forward_f32 / _algo takes such a
+ * tensor in the `guidance` argument: what is left of the fold is sigma = sum_k wb_k, the centre term (1 - sigma) H_0 (cspn.py:76)
+ * and the mask (cspn.py:81) -- no abs-sum, no reciprocal, no edge patching, aligned loads.  Results: those of CSPN_NORM_8SUM /
+ * _8SUM_ABS on the raw guidance up to the rounding of the division (<= 1e-6 relative; NaN where sum |G| = 0, as the reference).
+ * Every shape and n_iter the forward takes; no backward (the gradient w.r.t. wb is the producer's to chain: use the raw contract).
+ * cspn2d_normalize_f32 is that producer epilogue as a stand-alone kernel (norm_type 8SUM or 8SUM_ABS; tests, A/B timing):
+ * 36 B read + 32 B written per pixel.  cspn2d_forward_prenorm_f32 = cspn2d_forward_f32 with norm_type CSPN_NORM_PRENORM. */
+int cspn2d_normalize_f32(const float* guidance, float* wb, int B, int H, int W, int norm_type, cspn_stream_t stream);
+int cspn2d_forward_prenorm_f32(const float* wb, const float* blur, const float* sparse, float* out,
+                               int B, int H, int W, int n_iter, void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 /* ---- 2D backward: the gradient torch autograd computes through Affinity_Propagate.forward (reference cspn.py:42-83),
  * i.e. what reference cspn_pytorch/train.py:196-198 back-propagates through.
@@ -181,6 +183,15 @@ size_t cspn3d_backward_workspace_bytes(int B, int D, int H, int W, int n_iter);
 int cspn3d_backward_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat,
                         int B, int D, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+/* The same for C input channels on SHARED gates (reference cspn_paddle/README.md:56; the demo's optimiser differentiates the op,
+ * demo.py:65-75): feat, grad_out, grad_feat [B,C,D,H,W]; grad_gate [B,26,D,H,W] = the gate gradient SUMMED over the channels (what
+ * autograd accumulates into a shared tensor).  Any shape and n_iter >= 1; with n_iter >= 3 where cspn3d_multi_supported() holds, the
+ * level-keeping forward and the transposed sweep are ONE persistent launch each for all channels (gates resident in the registers
+ * across the channels) and the gate planes are written once.  Outputs may be NULL.  C = 1 is cspn3d_backward_f32. */
+size_t cspn3d_backward_multi_workspace_bytes(int B, int C, int D, int H, int W, int n_iter);
+int cspn3d_backward_multi_f32(const float* gate, const float* feat, const float* grad_out, float* grad_gate, float* grad_feat,
+                              int B, int C, int D, int H, int W, int n_iter,
+                              void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 /* ---- the steps right next to the path, on the device ----
  * cspn_metrics_f32: reference cspn_pytorch/utils.py:19-47 (evaluate_error) and loss.py:16-23 (Wighted_L1_Loss = MAE

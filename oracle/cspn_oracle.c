@@ -62,9 +62,14 @@ void cspn_oracle_set_threads(int n) {
 }
 
 /* norm_type: 0 = '8sum', 1 = '8sum_abs' (cspn.py:36), 2 = gates used as given,
- * centre-sited, no centre term (Paddle contract, cspn_paddle/README.md:54).   */
+ * centre-sited, no centre term (Paddle contract, cspn_paddle/README.md:54),
+ * 3 = 'prenorm': g IS the reference's gate_wb (what affinity_normalization,
+ * cspn.py:85-144, returns, cropped to the image): the loop of cspn.py:66-81 runs
+ * on it as it stands, gate_sum = its channel sum (cspn.py:139).
+ * wb_out != NULL: ALSO store the cropped gate_wb [8][H][W] (pinned by
+ * tests/golden/cspn2d_norm_golden.npz, vectors of the unmodified reference).  */
 static int cspn2d_one(const float* g, const float* blur, const float* sparse, float* out,
-                      int H, int W, int n_iter, int norm_type) {
+                      int H, int W, int n_iter, int norm_type, float* wb_out) {
     const int PH = H + 2, PW = W + 2;
     const size_t pn = (size_t)PH * PW, n = (size_t)H * W;
     float* gate_wb = (float*)calloc(8 * pn, sizeof(float)); /* [8][H+2][W+2] */
@@ -76,14 +81,18 @@ static int cspn2d_one(const float* g, const float* blur, const float* sparse, fl
         return -1;
     }
 
-    if (norm_type == 2) {
+    if (norm_type == 2 || norm_type == 3) {
         /* centre-sited: weight of neighbour k of pixel p is gate[k][p] itself.
          * Stored in the same "value used at padded coord (i+1,j+1)" layout.  */
         for (int k = 0; k < 8; ++k)
             for (int i = 0; i < H; ++i)
                 for (int j = 0; j < W; ++j)
                     gate_wb[k * pn + (size_t)(i + 1) * PW + (j + 1)] = g[k * n + (size_t)i * W + j];
-        for (size_t i = 0; i < n; ++i) gate_sum[i] = 1.0f; /* no centre term */
+        for (size_t i = 0; i < n; ++i) {
+            float gs = 0.0f;                               /* cspn.py:139 on the given gate_wb */
+            for (int k = 0; k < 8; ++k) gs += g[k * n + i];
+            gate_sum[i] = (norm_type == 2) ? 1.0f : gs;    /* 2: no centre term */
+        }
     } else {
         /* cspn.py:88-89 abs; :105-132 eight differently padded canvases      */
         for (int k = 0; k < 8; ++k) {
@@ -112,6 +121,10 @@ static int cspn2d_one(const float* g, const float* blur, const float* sparse, fl
             }
     }
 
+    if (wb_out)
+        for (int k = 0; k < 8; ++k)
+            for (int i = 0; i < H; ++i)
+                memcpy(wb_out + k * n + (size_t)i * W, gate_wb + k * pn + (size_t)(i + 1) * PW + 1, (size_t)W * sizeof(float));
     memcpy(res, blur, n * sizeof(float)); /* cspn.py:58,61 */
     for (int it = 0; it < n_iter; ++it) {
         /* cspn.py:69 pad_blur_depth: plane k is the depth padded by tuple k, so
@@ -144,19 +157,33 @@ static int cspn2d_one(const float* g, const float* blur, const float* sparse, fl
 /* guidance [B,8,H,W], blur [B,1,H,W], sparse [B,1,H,W] or NULL, out [B,1,H,W] */
 int cspn2d_oracle_f32(const float* guidance, const float* blur, const float* sparse, float* out,
                       int B, int H, int W, int n_iter, int norm_type) {
-    if (B < 0 || H <= 0 || W <= 0 || n_iter < 0 || norm_type < 0 || norm_type > 2) return -2;
+    if (B < 0 || H <= 0 || W <= 0 || n_iter < 0 || norm_type < 0 || norm_type > 3) return -2;
     const size_t n = (size_t)H * W;
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
         int e = cspn2d_one(guidance + (size_t)b * 8 * n, blur + (size_t)b * n,
                            sparse ? sparse + (size_t)b * n : NULL, out + (size_t)b * n,
-                           H, W, n_iter, norm_type);
+                           H, W, n_iter, norm_type, NULL);
         if (e) {
 #pragma omp atomic write
             err = e;
         }
     }
+    return err;
+}
+
+/* gate_wb of reference affinity_normalization (cspn.py:85-144), cropped: guidance [B,8,H,W] -> wb [B,8,H,W] */
+int cspn2d_oracle_gate_wb_f32(const float* guidance, float* wb, int B, int H, int W, int norm_type) {
+    if (B < 0 || H <= 0 || W <= 0 || norm_type < 0 || norm_type > 1) return -2;
+    const size_t n = (size_t)H * W;
+    int err = 0;
+    float* blur = (float*)calloc(n, sizeof(float));
+    float* out = (float*)malloc(n * sizeof(float));
+    if (!blur || !out) { free(blur); free(out); return -1; }
+    for (int b = 0; b < B; ++b)
+        if (cspn2d_one(guidance + (size_t)b * 8 * n, blur, NULL, out, H, W, 0, norm_type, wb + (size_t)b * 8 * n)) err = -1;
+    free(blur); free(out);
     return err;
 }
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcspn_oracle.so")
 _lib = None
 
-NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2}
+NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2, "prenorm": 3}
 
 
 def build(force=False):
@@ -31,6 +31,8 @@ def _load():
         lib.cspn2d_oracle_f32.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 5
         lib.cspn3d_oracle_f32.restype = ctypes.c_int
         lib.cspn3d_oracle_f32.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 6
+        lib.cspn2d_oracle_gate_wb_f32.restype = ctypes.c_int
+        lib.cspn2d_oracle_gate_wb_f32.argtypes = [fp, fp] + [ctypes.c_int] * 4
         lib.cspn_oracle_threads.restype = ctypes.c_int
         lib.cspn_oracle_set_threads.argtypes = [ctypes.c_int]
         _lib = lib
@@ -68,6 +70,19 @@ def cspn2d_oracle(guidance, blur_depth, sparse_depth=None, n_iter=24, norm_type=
     if rc:
         raise RuntimeError("cspn2d_oracle_f32 failed: %d" % rc)
     return out
+
+
+def cspn2d_gate_wb_oracle(guidance, norm_type="8sum"):
+    """guidance [B,8,H,W] -> gate_wb [B,8,H,W] of reference cspn.py:85-144 (affinity_normalization), cropped to the image: the
+    normalised, consumer-sited weights; cspn2d_oracle(gate_wb, ..., norm_type="prenorm") continues from there."""
+    g = _f32(guidance)
+    B, C, H, W = g.shape
+    assert C == 8
+    wb = np.empty_like(g)
+    rc = _load().cspn2d_oracle_gate_wb_f32(_ptr(g), _ptr(wb), B, H, W, NORM_TYPES[norm_type])
+    if rc:
+        raise RuntimeError("cspn2d_oracle_gate_wb_f32 failed: %d" % rc)
+    return wb
 
 
 def cspn3d_oracle(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):

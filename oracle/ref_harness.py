@@ -54,3 +54,16 @@ def reference_grads(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, nor
         out = m(g, h, sparse_depth)
         gg, gh = torch.autograd.grad(out, [g, h], grad_out)
     return out.detach(), gg, gh
+
+
+def reference_gate_wb(guidance, norm_type="8sum"):
+    """-> (gate_wb [B,8,H,W], gate_sum [B,1,H,W]) of /root/reference/cspn_pytorch/models/cspn.py:85-144 (affinity_normalization),
+    gate_wb cropped to the image like the reference crops the product at cspn.py:72: the consumer-sited, normalised weights the
+    loop of cspn.py:66-81 multiplies with.  The module's sum_conv only exists after a forward (cspn.py:42-51): one is run first."""
+    ref = load_reference_module()
+    m = ref.Affinity_Propagate(1, 3, norm_type)
+    B, _, H, W = guidance.shape
+    with torch.no_grad(), cuda_is_identity():
+        m(guidance, torch.zeros(B, 1, H, W), None)           # creates m.sum_conv exactly as the reference does
+        wb, gs = m.affinity_normalization(guidance)
+    return wb[:, :, 0, 1:-1, 1:-1].contiguous(), gs.contiguous()

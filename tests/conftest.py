@@ -35,6 +35,18 @@ def golden():
     return cases
 
 
+@pytest.fixture(scope="session")
+def norm_golden():
+    """gate_wb / gate_sum of the unmodified reference's affinity_normalization for cases of `golden` (tests/golden/make_norm_golden.py)"""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cspn2d_norm_golden.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = z[key]
+    return cases
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_lib():
     """The HIP library must exist before any test touches cspn_amd (hipcc cross-compiles on CPU)."""

@@ -176,3 +176,61 @@ def test_hip_3d_backward_config5_size_properties():
         dz, dy, dx = OFF3[k]
         want = a[:, 0] * pad[:, 1 + dz:1 + dz + D, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
         assert torch.allclose(g1[:, k], want, rtol=1e-6, atol=1e-7)
+
+
+# ---- round 5: gradient through C > 1 channels on SHARED gates (reference cspn_paddle/README.md:56, trained through at demo.py:65-75) ----
+def test_abi_exports_3d_backward_multi():
+    import cspn_amd
+    lib = cspn_amd.load()
+    one = 2 * 4 * 8 * 16 * 4
+    assert lib.cspn3d_backward_multi_workspace_bytes(2, 1, 4, 8, 16, 3) == lib.cspn3d_backward_workspace_bytes(2, 4, 8, 16, 3)
+    # three channels keep three times the level history; the persistent kernel's exchange buffers do not grow
+    assert lib.cspn3d_backward_multi_workspace_bytes(2, 3, 4, 8, 16, 3) - lib.cspn3d_backward_multi_workspace_bytes(2, 1, 4, 8, 16, 3) == 2 * 5 * one
+    assert lib.cspn3d_backward_multi_workspace_bytes(2, 0, 4, 8, 16, 3) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,D,H,W,N,signed", [(2, 3, 4, 5, 8, 1, False),        # the single chained call of the Paddle graph
+                                                 (1, 2, 3, 6, 7, 2, True),         # W % 4 != 0: scalar kernels
+                                                 (1, 3, 9, 17, 72, 3, False),      # fused sweeps (MULTI instantiations), partial tiles
+                                                 (2, 3, 20, 30, 200, 12, False),   # fused sweeps: several tiles and chunks, 12 steps
+                                                 (1, 4, 10, 9, 68, 4, True)])      # W % 8 == 4, signed gates
+def test_hip_3d_backward_multi_channel_vs_oracle_and_torch_autograd(B, C, D, H, W, N, signed):
+    """C channels on shared gates in ONE backward call: grad_feat per channel and grad_gate summed over the channels against the
+    oracle's adjoint per channel (and, on the smallest case, against torch autograd through plain torch ops); equal -- to summation
+    order -- to C single-channel calls of cspn3d_backward_f32"""
+    import cspn_amd
+    gen = torch.Generator().manual_seed(100 * C + N)
+    g = torch.rand(B, 26, D, H, W, generator=gen)
+    if signed:
+        g = g - 0.3
+    g = g / g.abs().sum(1, keepdim=True)
+    x = torch.rand(B, C, D, H, W, generator=gen)
+    go = torch.randn(B, C, D, H, W, generator=gen)
+    dG = np.zeros((B, 26, D, H, W), np.float64)
+    dF = np.zeros((B, C, D, H, W), np.float32)
+    for c in range(C):
+        a, b = cspn3d_backward_oracle(g.numpy(), x[:, c:c + 1].numpy(), go[:, c:c + 1].numpy(), N)
+        dG += a
+        dF[:, c:c + 1] = b
+    gg, gf = cspn_amd.cspn3d_backward_multi(g.cuda(), x.cuda(), go.cuda(), N)
+    cspn_amd.cspn3d_check_status()
+    assert _check(gg.cpu().numpy(), dG.astype(np.float32), "grad_gate") and _check(gf.cpu().numpy(), dF, "grad_feat")
+    # either output alone, and against the per-channel entry point
+    gg1, none = cspn_amd.cspn3d_backward_multi(g.cuda(), x.cuda(), go.cuda(), N, need_feat=False)
+    none2, gf1 = cspn_amd.cspn3d_backward_multi(g.cuda(), x.cuda(), go.cuda(), N, need_gate=False)
+    assert none is None and none2 is None and torch.equal(gg1, gg) and torch.equal(gf1, gf)
+    per = [cspn_amd.cspn3d_backward(g.cuda(), x[:, c:c + 1].contiguous().cuda(), go[:, c:c + 1].contiguous().cuda(), N) for c in range(C)]
+    assert torch.equal(gf, torch.cat([p[1] for p in per], 1))
+    ssum = sum(p[0] for p in per)
+    assert float((gg - ssum).abs().max()) <= 1e-5 * float(ssum.abs().max())
+    # through the autograd mirror of fluid.layers.affinity_propagate: one forward and one backward call for all channels
+    g1, x1 = g.cuda().requires_grad_(True), x.cuda().requires_grad_(True)
+    y = cspn_amd.affinity_propagate(x1, g1, 3, n_iter=N)
+    y.backward(go.cuda())
+    assert torch.equal(g1.grad, gg) and torch.equal(x1.grad, gf)
+    if B * C * D * H * W <= 2000:
+        gt, xt = g.clone().double().requires_grad_(True), x.clone().double().requires_grad_(True)
+        torch.cat([_torch_forward(gt, xt[:, c:c + 1], N) for c in range(C)], 1).backward(go.double())
+        assert _check(gg.cpu().numpy(), gt.grad.numpy()) and _check(gf.cpu().numpy(), xt.grad.numpy())
+        assert float((y.detach().cpu() - torch.cat([_torch_forward(g.double(), x[:, c:c + 1].double(), N) for c in range(C)], 1)).abs().max()) <= 1e-5

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from helpers import RTOL, make_inputs, rel_err
-from oracle import cspn2d_oracle, cspn3d_oracle
+from oracle import cspn2d_gate_wb_oracle, cspn2d_oracle, cspn3d_oracle
 from oracle import ref_harness
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,34 @@ def test_oracle_matches_golden(golden):
         out = cspn2d_oracle(c["guidance"], c["blur"], c.get("sparse"), N, NORMS[norm])
         err = rel_err(out, c["out"])
         assert err <= 1e-5, (name, err)  # oracle is pinned an order tighter than the product gate
+
+
+def test_gate_wb_oracle_and_prenorm_mode_match_golden(golden, norm_golden):
+    """SURVEY 8f-2 (normalisation done by the producer): the contract is the reference's OWN intermediate, gate_wb of
+    affinity_normalization (cspn.py:85-144).  tests/golden/cspn2d_norm_golden.npz holds it as the unmodified reference returned it
+    (tests/golden/make_norm_golden.py).  (1) the oracle's restatement of that function reproduces it; (2) the oracle's 'prenorm'
+    mode, fed the GOLDEN gate_wb, reproduces the golden outputs; (3) so does the numpy twin the emulator tests use."""
+    from tools.tswgen.run_emu import normalized_planes
+    assert len(norm_golden) >= 8
+    for name, n in norm_golden.items():
+        c = golden[name]
+        B, H, W, N, norm = [int(v) for v in c["meta"]]
+        wb = cspn2d_gate_wb_oracle(c["guidance"], NORMS[norm])
+        assert np.array_equal(np.isnan(wb), np.isnan(n["gate_wb"])), name
+        assert rel_err(wb, n["gate_wb"]) <= 1e-6, (name, rel_err(wb, n["gate_wb"]))
+        tw = normalized_planes(c["guidance"], norm)
+        assert np.array_equal(np.isnan(tw), np.isnan(n["gate_wb"])) and rel_err(tw, n["gate_wb"]) <= 1e-6, name
+        out = cspn2d_oracle(n["gate_wb"], c["blur"], c.get("sparse"), N, "prenorm")
+        assert np.array_equal(np.isnan(out), np.isnan(c["out"])), name
+        assert rel_err(out, c["out"]) <= 1e-5, (name, rel_err(out, c["out"]))
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="/root/reference not present (GPU box)")
+def test_norm_golden_is_what_the_reference_returns(golden, norm_golden):
+    for name, n in norm_golden.items():
+        c = golden[name]
+        wb, gs = ref_harness.reference_gate_wb(torch.from_numpy(c["guidance"]), NORMS[int(c["meta"][4])])
+        assert np.array_equal(wb.numpy(), n["gate_wb"], equal_nan=True) and np.array_equal(gs.numpy(), n["gate_sum"], equal_nan=True), name
 
 
 @pytest.mark.parametrize("channel_sum", ["conv3d", "sum"])

@@ -19,6 +19,10 @@ CASES = [
     (2, 17, 304, 5, 0, True, False, True),    # two bands, shares that start / end mid-image, NaN patch
     (1, 20, 512, 2, 1, True, False, False),
     (1, 14, 256, 2, 2, True, True, False),    # pre-normalised gates, continuation pass (H_t0 != H_0)
+    # norm 3 = CSPN_NORM_PRENORM (round 5): the kernel reads the reference's gate_wb (numpy twin of cspn2d_normalize_f32
+    # applied to the raw guidance), the oracle sees the RAW tensors with '8sum'
+    (2, 17, 304, 5, 3, True, False, True),    # two bands, mid-image share ends, NaN weights from a zero-guidance patch, mask
+    (2, 14, 256, 2, 3, False, True, False),   # continuation pass
 ]
 
 
@@ -32,7 +36,8 @@ def test_emulated_asm_loop_vs_oracle(B, H, W, n_wg, norm, sparse, hin, zp):
         assert np.isnan(ref).any()
 
 
-@pytest.mark.parametrize("B,H,W,ncu,norm,sparse", [(2, 21, 304, 3, 0, True), (1, 150, 516, 4, 1, False), (2, 60, 304, 3, 2, True)])
+@pytest.mark.parametrize("B,H,W,ncu,norm,sparse", [(2, 21, 304, 3, 0, True), (1, 150, 516, 4, 1, False), (2, 60, 304, 3, 2, True),
+                                                   (2, 30, 304, 3, 3, True)])
 def test_emulated_asm_loop_on_linear_plan_pieces_that_change_band(B, H, W, ncu, norm, sparse):
     """round 4: the forward passes' linear plan -- a workgroup's piece may end one band's rows and continue with the next band's
     (the retirement re-derives the owned-lane mask from the row's descriptor): every pixel still comes out right"""

@@ -9,7 +9,7 @@ timeout 1500 python -m pytest tests -m gpu -q -x > ${O}_pytest.log 2>&1; echo "p
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 T0=$(date +%s.%N)
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > ${O}_bench_driver.json 2> ${O}_bench.err
-echo "driver command wall s: $(echo "$(date +%s.%N) - $T0" | bc)" | tee ${O}_bench_driver_wall.txt
+python -c "import time,sys; print(\"driver command wall s: %.1f\" % (time.time() - float(sys.argv[1])))" $T0 | tee ${O}_bench_driver_wall.txt
 python - <<P
 import json
 d=json.load(open('${O}_bench_driver.json'))

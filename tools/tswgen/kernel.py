@@ -9,7 +9,9 @@ register is assigned by hand and the 24 phases of a wave's ring counter are unro
 The C++ side (cspn2d_tsw.hip) provides kernel arguments in fixed SGPRs and the LDS allocation.
 
 Register / LDS maps are module constants; `build(cfg)` returns an isa.Prog.
-cfg: norm (0 '8sum', 1 '8sum_abs', 2 'none'), sparse (bool), hin (bool: level-0 values come from a previous pass),
+cfg: norm (0 '8sum', 1 '8sum_abs', 2 'none', 3 'prenorm': the caller hands over what reference affinity_normalization returns
+-- gate_wb, cspn.py:85-144: normalised and consumer-sited -- so cooking is only sigma = sum_k w_k, c' = (1 - sigma) H0 and the
+mask fold: SURVEY 8f-2, second alternative), sparse (bool), hin (bool: level-0 values come from a previous pass),
 n_iter (only 24 for now).
 """
 from .isa import Prog, V, S, EXEC, VCC, schedule, check_hazards, expand_pseudos
@@ -137,7 +139,10 @@ class Gen(object):
         self.s8 = cfg.get("s8", False)
         if self.s8:
             assert not self.adj and not self.hist
-        self.sited = (self.norm != 2 or self.adj) and not self.s8   # guidance plane k is read at (y + dy_k, x + dx_k)
+        self.given = self.norm in (2, 3)   # coefficients are used as given, centre-sited (3: with the centre term, 2: without)
+        if self.norm == 3:
+            assert not self.adj and not self.hist and not self.s8
+        self.sited = (not self.given or self.adj) and not self.s8   # guidance plane k is read at (y + dy_k, x + dx_k)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []
         self.estubs = []
@@ -697,7 +702,13 @@ class Gen(object):
             for k in range(8):
                 self.e("v_and_b32", g[k][0], [0x7fffffff, g[k][0]])
                 self.e("v_and_b32", g[k][1], [0x7fffffff, g[k][1]])
-        if norm != 2:
+        if norm == 3:
+            # prenorm: the planes ARE the w_k(p) of reference cspn.py:138; what is left of the fold is the centre term (cspn.py:76)
+            self.e("v_pk_add_f32", tt, [g[0], g[1]])
+            for k in range(2, 8):
+                self.e("v_pk_add_f32", tt, [tt, g[k]])
+            self.fma(cc, tt, h0, h0, neg_lo=[1, 0, 0], neg_hi=[1, 0, 0], keep=True)  # (1 - sigma) * H0
+        elif norm != 2:
             self.e("v_add_f32", sx, [g[0][0].abs(), g[1][0].abs()])
             self.e("v_add_f32", sy, [g[0][1].abs(), g[1][1].abs()])
             for k in range(2, 8):
@@ -733,7 +744,7 @@ class Gen(object):
                 self.e("v_cmp_lt_f32", S(T[6].i, 2), [PEND_SP[i], 0])
                 self.e("v_cndmask_b32", mm[i], [mm[i], -1.0, S(T[6].i, 2)])
                 self.e("v_sub_f32", om[i], [1.0, mm[i]])
-            if norm != 2:
+            if not self.given:
                 self.e("v_pk_mul_f32", scale, [scale, om])
             else:
                 self.mov(scale[0], om[0])
@@ -743,7 +754,7 @@ class Gen(object):
         nw = "nocookwrite" in self.ab
         deferred = []   # the eight coefficient planes are written from the caller's main region, between its FMAs
         for k in range(8):
-            if norm != 2 or self.sparse:
+            if not self.given or self.sparse:
                 self.e("v_pk_mul_f32", g[k], [g[k], scale])
             if not nw:
                 deferred.append((ringw, g[k], k * 16))

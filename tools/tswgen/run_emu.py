@@ -36,6 +36,9 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
     prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, hist_every=hist_every, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {}),
                         **(cfg_extra or {})), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
+    if norm == 3:   # prenorm: the kernel reads what reference affinity_normalization returns for the RAW guidance g ('8sum'); the oracle
+        g_dev = normalized_planes(g, 0)    # below still sees the raw tensors
+
     histbuf = np.full((23 + 8, B, 1, H, W), np.nan, np.float32) if hist else None   # + the 8 folded coefficient planes
     from .plan import plan_bands
     nb = len(plan_bands(W, n_iter))
@@ -103,7 +106,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         # oracle for a continuation pass: propagate hinv with blur as H0 ... the oracle has no such entry; emulate with numpy
         ref = ref_hin(g, blur, sp, hinv, n_iter, norm)
     else:
-        ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none"][norm])
+        ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none", "8sum"][norm])
     if hist:
         assert not hin
         npl = 24 // hist_every - 1   # level planes: levels hist_every, 2 hist_every ..
@@ -156,6 +159,20 @@ def sited8(g, norm):
     return out
 
 
+def normalized_planes(g, norm):
+    """gate_wb of reference cspn.py:85-144 as [B,8,H,W]: w_k(p) = G_k(p) / sum_j |G_j(p)|, G_k(p) = g~_k(p + off_k), zero outside
+    the image (IEEE division: 0/0 = NaN) -- numpy twin of cspn2d_normalize_f32"""
+    B, _, H, W = g.shape
+    gp = np.abs(g) if norm == 1 else g
+    G = np.zeros_like(g)
+    for k in range(8):
+        pad = np.zeros((B, H + 2, W + 2), np.float32)
+        pad[:, 1:-1, 1:-1] = gp[:, k]
+        G[:, k] = pad[:, 1 + K.DY[k]:1 + K.DY[k] + H, 1 + K.DX[k]:1 + K.DX[k] + W]
+    with np.errstate(all="ignore"):
+        return (G / np.abs(G).sum(1, keepdims=True)).astype(np.float32)
+
+
 def fill_table(emu, tab_wg):
     """the C++ part of the kernel (cspn2d_tsw.hip: tsw_fill_table) writes the workgroup's descriptor table into LDS before
     the generated block starts; the emulator does the same with the table of tools/tswgen/plan.py"""
@@ -184,6 +201,8 @@ def folded_planes(g, sp, norm):
 
 def ref_hin(g, blur, sp, hin, n_iter, norm):
     """numpy reference for a continuation pass (H_t starts at hin, H0 = blur), restating oracle/cspn_oracle.c"""
+    if norm == 3:
+        norm = 0   # (prenorm: g is the raw guidance, the kernel got its '8sum' normalisation)
     B, _, H, W = g.shape
     DY, DX = K.DY, K.DX
     gp = np.abs(g) if norm == 1 else g
