@@ -126,6 +126,71 @@ def parity_check(out, g, h, s, n_iter, norm, rtol=1e-4):
             "against": "oracle/cspn_oracle.c (pinned to the reference's golden vectors)"}
 
 
+_REFOPS_CHILD = r"""
+import json, os, sys, time
+import torch
+sys.path.insert(0, sys.argv[1])
+import bench
+from tools.torch_ops_baseline import affinity_propagate_torch_ops
+H, W, n_iter, sparse, scale, norm, cores, budget = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] == "1", float(sys.argv[6]), sys.argv[7], int(sys.argv[8]), float(sys.argv[9])
+g, h, s = bench.synth(1, H, W, scale, sparse, "cpu", first=0, seed0=4242)
+t_start = time.perf_counter()
+for nthr in sorted({min(cores, 16), min(cores, 64), cores}):
+    torch.set_num_threads(nthr)
+    affinity_propagate_torch_ops(g, h, s, 1, norm)            # thread pool, primitive caches
+    t0 = time.perf_counter()
+    affinity_propagate_torch_ops(g, h, s, 2, norm)            # normalisation + 2 iterations: what a full run will cost
+    t2 = time.perf_counter() - t0
+    projected = t2 * (n_iter + 2.0) / 4.0
+    left = budget - (time.perf_counter() - t_start)
+    if projected > left:
+        print(json.dumps({"threads": nthr, "skipped": "a %d-iteration forward of ONE image projects to %.1f s (normalisation + 2 iterations took %.2f s); %.1f s of the leg's budget left" % (n_iter, projected, t2, left),
+                          "projected_value": round(H * W * n_iter / 1e6 / projected, 2)}), flush=True)
+        continue
+    reps, t_total = 0, 0.0
+    while reps < 1 or (t_total < 1.5 and reps < 8):
+        t0 = time.perf_counter()
+        affinity_propagate_torch_ops(g, h, s, n_iter, norm)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    print(json.dumps({"threads": torch.get_num_threads(), "value": round(H * W * n_iter * reps / 1e6 / t_total, 2), "reps": reps}), flush=True)
+"""
+
+
+def reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, cores, budget_s=24.0):
+    """tools/torch_ops_baseline.py -- the op sequence reference cspn.py:42-83 launches, pinned to the unmodified reference's golden
+    vectors -- on torch-CPU, ONE image per forward, at 16 / 64 / all host threads.  Runs in a CHILD process (its own OpenMP runtime:
+    in this process the oracle's 256 spinning OpenMP threads made torch-CPU 100x slower, profiles/r05_cpu_baseline_notes.md) and is
+    bounded: a thread count whose full forward projects beyond the leg's budget is reported as skipped with the projection."""
+    import subprocess
+    try:
+        env = dict(os.environ, OMP_WAIT_POLICY="PASSIVE", HIP_VISIBLE_DEVICES="")
+        p = subprocess.run([sys.executable, "-c", _REFOPS_CHILD, ROOT, str(H), str(W), str(n_iter), "1" if sparse else "0", str(scale), norm,
+                            str(cores), str(budget_s)], capture_output=True, text=True, timeout=budget_s + 30, env=env)
+        legs = [json.loads(line) for line in p.stdout.splitlines() if line.startswith("{")]
+        if not legs:
+            return {"error": "no result (rc %d): %s" % (p.returncode, p.stderr[-300:])}
+    except subprocess.TimeoutExpired as ex:
+        legs = [json.loads(line) for line in (ex.stdout or b"").decode("utf-8", "replace").splitlines() if line.startswith("{")]
+        if not legs:
+            return {"error": "timed out after %.0f s without a result" % (budget_s + 30)}
+    except Exception as ex:   # noqa: BLE001 -- reported in the line, never hidden
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    done = [x for x in legs if "value" in x]
+    allc = [x for x in legs if x["threads"] == cores]
+    best = max(done, key=lambda x: x["value"]) if done else None
+    out = {"unit": "Mpix*iters/s", "kind": "reference_op_sequence", "by_threads": legs,
+           "sample": "1 image %dx%d x %d iters per repetition, tools/torch_ops_baseline.py (the torch op sequence of reference cspn.py:42-83 "
+                     "incl. its 1x1x1 Conv3d channel sum, pinned to the unmodified reference's golden vectors) on torch-CPU %s in a child "
+                     "process; `value` / `cores` = the fastest thread count that ran, `all_cores` = torch.set_num_threads(os.cpu_count()) "
+                     "as SURVEY 8d prescribes" % (H, W, n_iter, torch.__version__)}
+    if best:
+        out["value"], out["cores"] = best["value"], best["threads"]
+    if allc:
+        out["all_cores"] = allc[0]
+    return out
+
+
 def cpu_baseline(H, W, n_iter, sparse, scale, norm):
     """Two CPU legs on this host's cores, each on a bounded sample of the same workload:
     (1) kind "port": oracle/cspn_oracle.c (C restatement of reference cspn.py:42-172, OpenMP over images, one image per thread) on
@@ -172,34 +237,7 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
             set_oracle_threads(cores)
     except Exception as ex:   # noqa: BLE001
         res["port_on_64_threads"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
-    try:
-        from tools.torch_ops_baseline import affinity_propagate_torch_ops
-        legs = []
-        budget_s, t_leg0 = 25.0, time.perf_counter()   # bounded: on 256 threads torch-CPU needs ~12 s for ONE image (r05 measurement)
-        for nthr in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
-            if time.perf_counter() - t_leg0 > budget_s:
-                break
-            torch.set_num_threads(nthr)
-            gb, hb, sb = g[:1], h[:1], (s[:1] if s is not None else None)
-            affinity_propagate_torch_ops(gb, hb, sb, 1, norm)   # warm (primitive caches, thread pool)
-            reps, t_total = 0, 0.0
-            while reps < 1 or (t_total < 2.0 and reps < 8):
-                t0 = time.perf_counter()
-                affinity_propagate_torch_ops(gb, hb, sb, n_iter, norm)
-                t_total += time.perf_counter() - t0
-                reps += 1
-            legs.append({"threads": torch.get_num_threads(), "value": round(H * W * n_iter * reps / 1e6 / t_total, 2), "reps": reps})
-        allc = legs[0]
-        best = max(legs, key=lambda x: x["value"])
-        res["reference_op_sequence"] = {
-            "value": allc["value"], "unit": "Mpix*iters/s", "cores": allc["threads"], "kind": "reference_op_sequence",
-            "best": {"value": best["value"], "cores": best["threads"]}, "by_threads": legs,
-            "sample": "1 image %dx%d x %d iters per repetition, tools/torch_ops_baseline.py (the torch op sequence of reference cspn.py:42-83 "
-                      "incl. its 1x1x1 Conv3d channel sum, pinned to the unmodified reference's golden vectors) on torch-CPU %s; `value` "
-                      "is at torch.set_num_threads(os.cpu_count()) as SURVEY 8d prescribes, `best` the fastest thread count tried"
-                      % (H, W, n_iter, torch.__version__)}
-    except Exception as ex:   # noqa: BLE001 -- reported in the line, never hidden
-        res["reference_op_sequence"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    res["reference_op_sequence"] = reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, cores)
     return res
 
 

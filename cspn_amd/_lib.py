@@ -136,6 +136,8 @@ def load_hooks():
     h.cspn_debug_tsw_dump_plan.argtypes = [c_int] * 5 + [vp, vp, vp]
     h.cspn_debug_forward2d_plan.restype = c_int
     h.cspn_debug_forward2d_plan.argtypes = [vp] * 4 + [c_int] * 6 + [vp, vp]
+    h.cspn_debug_3d_geo.restype = c_int
+    h.cspn_debug_3d_geo.argtypes = [c_int] * 5 + [ip]
     h.cspn_debug_3d_persistent_error.restype = c_int
     h.cspn_debug_3d_persistent_error.argtypes = [vp] + [c_int] * 4
     h.cspn_debug_3d_persistent_forward.restype = c_int

@@ -54,7 +54,10 @@ struct Geo3 {
     int S;                   // owned x-extent of a chunk
     int nchunk;              // chunks per launch: the volumes stand side by side along x, `pitch` columns apart (>= W + 4: the
     int pitch, vw;           // columns between them are never inside a volume, so nothing flows across), vw = B pitch - 4
-    int n_wg;                // workgroups launched (>= tz * ty * cx)
+    int n_wg;                // tiles = tz * ty * cx (the exchange buffers and the XCC table are indexed by tile)
+    int n_launch;            // workgroups launched: n_wg, or 8 * (tiles per block) with the XCD-aware placement
+    int bz, by, bx;          // XCD-aware placement (round 5): the tile grid is cut into <= 8 blocks of bz x by x bx tiles, block k is
+    int nby, nbx;            // given to the workgroups with id % 8 == k (ids 8 apart share an XCD: observed, never relied on); bz = 0: off
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
     int mute;                // MUTE instantiation (test-hook library) only: the workgroup that never publishes
     int C;                   // MULTI instantiation only: value channels that share the gates (feat / out are [B][C][V])
@@ -71,6 +74,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16_sc1(float* p, float4 v) {
     const v4f x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
+__device__ __forceinline__ void st16_l2(float* p, float4 v) {   // no scope bits: the line stays (dirty) in this XCD's L2
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(x) : "memory");
 }
 
 // published boundary of a tile, in 16-byte quads = up to three values + the step tag in the fourth word.  Thread xg
@@ -136,15 +144,45 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define P3_STAMP(k)
 #define P3_CHUNK(k)
 #endif
-    const int tid = threadIdx.x, wg = blockIdx.x;
+    __shared__ unsigned long long s_rowl2;   // bit (lz * TY + ly): every reader of that boundary row's quads runs on THIS XCD
+    __shared__ unsigned s_xl2;               // bit (side * TZ + lz): the same for the line of x-face quads of plane lz
+    const int tid = threadIdx.x;
     const size_t HW = (size_t)g.H * g.W, V = (size_t)g.D * HW, total = (size_t)g.B * V;
     const int nch = MULTI ? g.C : 1;
     const int FBS = MULTI ? g.C * (int)V : (int)V;   // volume stride of the value tensors in floats ([B][C][V])
     float4* X = reinterpret_cast<float4*>(scratch + 2 * total);   // [2][n_wg][NQ] published boundaries
-    const int tiles = g.tz * g.ty * g.cx;
-    const bool have_tile = wg < tiles;
-    const int ix = wg % g.cx, iy = (wg / g.cx) % g.ty, iz = wg / (g.cx * g.ty);
-    if (tid == 0) s_bail = 0;
+    // ---- which tile this workgroup owns.  XCD-aware placement (round 5): workgroup ids 8 apart have so far always shared an XCD
+    // (MI355X_MICROARCH.md: "observed, for speed only"), so block k of the tile grid goes to the ids = k mod 8 -- a tile's
+    // neighbours are then mostly on its own XCD and their exchange stays in that XCD's L2.  Nothing below RELIES on the
+    // placement: every workgroup publishes the XCC it really runs on, and a row is stored L2-resident only if every workgroup
+    // that reads it has published the same XCC (s_rowl2 / s_xl2); everything else goes write-through as before.
+    int ix, iy, iz;
+    bool have_tile;
+    {
+        const int b = blockIdx.x;
+        if (g.bz > 0) {
+            const int k = b & 7, s = b >> 3, bsz = g.bz * g.by * g.bx;
+            const int kx = k % g.nbx, ky = (k / g.nbx) % g.nby, kz = k / (g.nbx * g.nby);
+            const int sx = s % g.bx, sy = (s / g.bx) % g.by, sz = s / (g.bx * g.by);
+            ix = kx * g.bx + sx; iy = ky * g.by + sy; iz = kz * g.bz + sz;
+            have_tile = s < bsz && iz < g.tz;   // (blocks beyond the grid: fewer than 8 blocks)
+        } else {
+            ix = b % g.cx; iy = (b / g.cx) % g.ty; iz = b / (g.cx * g.ty);
+            have_tile = b < g.tz * g.ty * g.cx;
+        }
+    }
+    const int wg = have_tile ? (iz * g.ty + iy) * g.cx + ix : 0;   // the TILE's number: exchange buffers, XCC table, mute
+    unsigned* xcctab = sync + 1024;   // [n_wg] 1 + XCC id of the workgroup that owns the tile (cleared by the launch's memset)
+    if (tid == 0) {
+        s_bail = 0;
+        s_rowl2 = 0ull;
+        s_xl2 = 0u;
+        if (have_tile) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            __hip_atomic_store(xcctab + wg, 1u + (xcc & 0xfu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sc1: write-through)
+        }
+    }
     // byte offsets of a thread's two gate quads in chunk cc (what the chunk prologue below calls voff0 / voff1)
     auto gate_offs = [&](int cc, int tc, unsigned& v0, unsigned& v1) {
         const int x0n = cc * g.S - g.halo + ix * TX;
@@ -173,6 +211,44 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
         for (int k = 0; k < NPRE / 2; ++k) park_gate(0, k, tc);
     }
+    __syncthreads();   // (s_rowl2 / s_xl2 / s_bail initialised)
+    if (have_tile && tid < 64) {
+        // Thread r < 64 = boundary row (lz, ly) = (r / TY, r % TY): are all tiles that read this row's quads on my XCD?
+        // Readers: the tiles at (dz, dy) != (0, 0) with dz in {0, -1 if lz == 0, +1 if lz == TZ - 1}, dy likewise, dx = 0.
+        // A neighbour's XCC is polled a bounded number of times (all workgroups of a grid start within a microsecond of each
+        // other and this runs under the first chunk's LDS-DMA requests); if it does not show, the row simply stays
+        // write-through.  Done HERE, before any gate register is live: inside the chunk loop it cost ten spilled registers.
+        unsigned mine_x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine_x));
+        mine_x = 1u + (mine_x & 0xfu);
+        auto same_xcd = [&](int dz, int dy, int dx) -> bool {
+            const int tz2 = iz + dz, ty2 = iy + dy, tx2 = ix + dx;
+            if (tz2 < 0 || tz2 >= g.tz || ty2 < 0 || ty2 >= g.ty || tx2 < 0 || tx2 >= g.cx) return true;   // nobody there
+            const unsigned* pe = xcctab + (tz2 * g.ty + ty2) * g.cx + tx2;
+            unsigned v = 0;
+            for (int t = 0; t < 2048 && v == 0; ++t) {
+                v = __hip_atomic_load(pe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            return v == mine_x;
+        };
+        const int rz = tid >> 3, ry = tid & 7;
+        bool rl = true;
+        for (int dz = (rz == 0 ? -1 : 0); dz <= (rz == TZ - 1 ? 1 : 0); ++dz)
+            for (int dy = (ry == 0 ? -1 : 0); dy <= (ry == TY - 1 ? 1 : 0); ++dy)
+                if (dz || dy) rl = rl && same_xcd(dz, dy, 0);
+        if (rl) atomicOr(&s_rowl2, 1ull << tid);
+        if (tid < 2 * TZ) {
+            // the 128-byte line of x-face quads of plane lz = tid % TZ, side = tid / TZ: read by the tiles at dx = -1 (side 0)
+            // / +1 (side 1), dy in {-1, 0, 1} (the line holds all eight rows of the plane), dz as above
+            const int pz = tid % TZ, dx = tid < TZ ? -1 : 1;
+            bool xl = true;
+            for (int dz = (pz == 0 ? -1 : 0); dz <= (pz == TZ - 1 ? 1 : 0); ++dz)
+                for (int dy = -1; dy <= 1; ++dy) xl = xl && same_xcd(dz, dy, dx);
+            if (xl) atomicOr(&s_xl2, 1u << tid);
+        }
+    }
+    __syncthreads();   // s_rowl2 / s_xl2 are complete (and s_bail initialised) before anybody publishes
     {
         for (int c = 0; c < g.nchunk; ++c) {
             const unsigned round = (unsigned)c;
@@ -499,13 +575,30 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             float4* mine = X + ((size_t)(target & 1) * g.n_wg + wg) * NQ;
                             float4* rowq = mine + (lz * TY + ly) * XG + (lx >> 3);
                             const float tagf = __uint_as_float(target);
+                            // a row all of whose readers run on this XCD is stored without scope bits (the line stays in the
+                            // XCD's L2, where the readers' sc1 loads find it: no memory-side round trip, no memory-side bytes);
+                            // every other row write-through (sc1) as before.  Per 128-byte line, never mixed inside one.
                             if (lz == 0 || lz == TZ - 1 || ly == 0 || ly == TY - 1) {
-                                st16_sc1(reinterpret_cast<float*>(rowq), make_float4(acc[0], acc[1], acc[2], tagf));
-                                st16_sc1(reinterpret_cast<float*>(rowq + NROWS * XG), make_float4(acc[3], acc[4], acc[5], tagf));
-                                st16_sc1(reinterpret_cast<float*>(rowq + 2 * NROWS * XG), make_float4(acc[6], acc[7], 0.f, tagf));
+                                if ((s_rowl2 >> (lz * TY + ly)) & 1ull) {
+                                    st16_l2(reinterpret_cast<float*>(rowq), make_float4(acc[0], acc[1], acc[2], tagf));
+                                    st16_l2(reinterpret_cast<float*>(rowq + NROWS * XG), make_float4(acc[3], acc[4], acc[5], tagf));
+                                    st16_l2(reinterpret_cast<float*>(rowq + 2 * NROWS * XG), make_float4(acc[6], acc[7], 0.f, tagf));
+                                } else {
+                                    st16_sc1(reinterpret_cast<float*>(rowq), make_float4(acc[0], acc[1], acc[2], tagf));
+                                    st16_sc1(reinterpret_cast<float*>(rowq + NROWS * XG), make_float4(acc[3], acc[4], acc[5], tagf));
+                                    st16_sc1(reinterpret_cast<float*>(rowq + 2 * NROWS * XG), make_float4(acc[6], acc[7], 0.f, tagf));
+                                }
                             }
-                            if (lx == 0) st16_sc1(reinterpret_cast<float*>(mine + NQA + lz * TY + ly), make_float4(acc[0], 0.f, 0.f, tagf));
-                            if (lx == TX - 8) st16_sc1(reinterpret_cast<float*>(mine + NQA + NROWS + lz * TY + ly), make_float4(acc[7], 0.f, 0.f, tagf));
+                            if (lx == 0) {
+                                float* q = reinterpret_cast<float*>(mine + NQA + lz * TY + ly);
+                                if ((s_xl2 >> lz) & 1u) st16_l2(q, make_float4(acc[0], 0.f, 0.f, tagf));
+                                else st16_sc1(q, make_float4(acc[0], 0.f, 0.f, tagf));
+                            }
+                            if (lx == TX - 8) {
+                                float* q = reinterpret_cast<float*>(mine + NQA + NROWS + lz * TY + ly);
+                                if ((s_xl2 >> (TZ + lz)) & 1u) st16_l2(q, make_float4(acc[7], 0.f, 0.f, tagf));
+                                else st16_sc1(q, make_float4(acc[7], 0.f, 0.f, tagf));
+                            }
                         }
                         // ---- the halo shell: 36 rows of the neighbours above / below / beside in y (24 quads each) and the 200 voxels
                         // beside the tile in x (one value of a neighbour's first or last quad), polled until their tag is this step's
@@ -671,7 +764,7 @@ int resident_wgs() {
     return d.wgs;
 }
 
-Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
+Geo3 make_geo3(int B, int D, int H, int W, int n_iter, bool placement = true) {
     Geo3 g{};
     g.B = B; g.D = D; g.H = H; g.W = W; g.n_iter = n_iter;
     g.halo = 4 * ((n_iter + 3) / 4);
@@ -686,6 +779,35 @@ Geo3 make_geo3(int B, int D, int H, int W, int n_iter) {
     g.S = g.cx * TX - 2 * g.halo;
     g.nchunk = g.S > 0 ? (g.vw + g.S - 1) / g.S : 0;
     g.n_wg = per_col * g.cx;
+    g.n_launch = g.n_wg;
+    g.bz = g.by = g.bx = 0;
+    g.nby = g.nbx = 1;
+    // XCD-aware placement: cut the tz x ty x cx tile grid into at most 8 equal blocks of at most 32 tiles and give block k to the
+    // workgroup ids = k (mod 8).  Among the exact cuts with the most blocks (every XCD busy) take the one with the smallest
+    // cross-block surface, in quads a tile fetches per step: z face LY x QROW, y face TZ x QROW, x face LZ x LY.  Off (bz = 0, plain
+    // order) when the device is not 8 x 32 CUs, when there are fewer tiles than 16, or when no exact cut gives at least 4 blocks.
+    if (placement && resident_wgs() == 256 && g.n_wg >= 16) {
+        long best = -1;
+        int best_blocks = 0;
+        for (int bz = 1; bz <= g.tz; ++bz) {
+            if (g.tz % bz) continue;
+            for (int by = 1; by <= g.ty; ++by) {
+                if (g.ty % by) continue;
+                for (int bx = 1; bx <= g.cx; ++bx) {
+                    if (g.cx % bx) continue;
+                    const int nz = g.tz / bz, ny = g.ty / by, nx = g.cx / bx, blocks = nz * ny * nx;
+                    if (blocks > 8 || blocks < 4 || bz * by * bx > 32) continue;
+                    const long surf = (long)(nz - 1) * g.ty * g.cx * (LY * QROW) + (long)(ny - 1) * g.tz * g.cx * (TZ * QROW) +
+                                      (long)(nx - 1) * g.tz * g.ty * (LZ * LY);
+                    if (blocks > best_blocks || (blocks == best_blocks && surf < best)) {
+                        best_blocks = blocks; best = surf;
+                        g.bz = bz; g.by = by; g.bx = bx; g.nby = ny; g.nbx = nx;
+                    }
+                }
+            }
+        }
+        if (g.bz > 0) g.n_launch = 8 * g.bz * g.by * g.bx;
+    }
     return g;
 }
 
@@ -696,7 +818,7 @@ bool persistent3d_supported(int B, int D, int H, int W, int n_iter) {
     const Geo3 g = make_geo3(B, D, H, W, n_iter);
     // worth it only when a chunk owns clearly more than it recomputes, and the device can hold it
     // (lane offsets into the gate tensor are 32-bit byte offsets)
-    return g.pitch >= LXU && g.cx >= 1 && g.n_wg <= resident_wgs() && g.S >= 4 * g.halo && g.nchunk < (1 << 24) &&
+    return g.pitch >= LXU && g.cx >= 1 && g.n_launch <= resident_wgs() && g.S >= 4 * g.halo && g.nchunk < (1 << 24) &&
            (long long)B * 26 * D * H * W * 4 < (1LL << 32);
 }
 
@@ -714,7 +836,7 @@ size_t persistent3d_workspace(int B, int D, int H, int W) {
 // cprime != nullptr: gate holds the 26 folded planes [26][B][V] and cprime the constant term (normalising / masked modes)
 static int persistent3d_launch(const float* gate, const float* feat, const float* cprime, float* out, float* levels, int lv0, int lvs,
                                bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt, int C = 1) {
-    Geo3 g = make_geo3(B, D, H, W, n_iter);
+    Geo3 g = make_geo3(B, D, H, W, n_iter, opt.placement);
     g.C = C;
     g.lv0 = lv0;
     g.lvs = lvs;
@@ -772,9 +894,9 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
                    : mute >= 0 ? (const void*)cspn3d_persistent_kernel<false, false, true> : (const void*)cspn3d_persistent_kernel<false, false>;
     const bool coop = opt.coop;
     if (coop && !capturing) {
-        e = hipLaunchCooperativeKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+        e = hipLaunchCooperativeKernel(fn, dim3(g.n_launch), dim3(NTP), args, 0, st);
     } else if (capturing) {
-        e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+        e = hipLaunchKernel(fn, dim3(g.n_launch), dim3(NTP), args, 0, st);
     } else {
         if (!d.last) {
             e = hipEventCreateWithFlags(&d.last, hipEventDisableTiming);
@@ -783,7 +905,7 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
             e = hipStreamWaitEvent(st, d.last, 0);
             if (e != hipSuccess) { set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); return (int)e; }
         }
-        e = hipLaunchKernel(fn, dim3(g.n_wg), dim3(NTP), args, 0, st);
+        e = hipLaunchKernel(fn, dim3(g.n_launch), dim3(NTP), args, 0, st);
         if (e == hipSuccess) {
             e = hipEventRecord(d.last, st);
             d.last_stream = st;
@@ -840,6 +962,13 @@ int persistent3d_forward_multi(const float* gate, const float* feat, float* out,
 int persistent3d_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, void* ws,
                          hipStream_t st) {
     return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, st);
+}
+
+// (test-hook library) the plan of a persistent launch: info[9] = tz, ty, cx, tiles, workgroups launched, bz, by, bx (0: plain order), chunks
+void persistent3d_geo(int B, int D, int H, int W, int n_iter, int* info) {
+    const Geo3 g = make_geo3(B, D, H, W, n_iter);
+    const int v[9] = {g.tz, g.ty, g.cx, g.n_wg, g.n_launch, g.bz, g.by, g.bx, g.nchunk};
+    for (int i = 0; i < 9; ++i) info[i] = v[i];
 }
 
 // (test-hook library) the error word of the last run in this workspace (0 ok, 2 neighbour-quad timeout); synchronises

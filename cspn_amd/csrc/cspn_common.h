@@ -48,12 +48,13 @@ int persistent3d_forward_folded(const float* wf, const float* feat, float* out, 
                                 hipStream_t st);
 // launch options only the test-hook library sets (csrc/cspn_test_hooks.hip): mute = the workgroup that never publishes its
 // boundary (its neighbours then run into the poll timeout), coop = hipLaunchCooperativeKernel instead of the event chain
-struct P3Options { int mute = -1; bool coop = false; };
+struct P3Options { int mute = -1; bool coop = false; bool placement = true; /* false: tiles in plain workgroup order (A/B of the XCD-aware placement) */ };
 // the same run for the backward: adjoint = transposed operator; levels + (lv0 + it * lvs) volumes receive step it < n_iter
 // C > 1: feat / out / the level volumes hold C value channels per volume ([B][C][V]) on shared gates (the MULTI instantiations)
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,
                      int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt = P3Options(), int C = 1);
 int persistent3d_error_word(const void* ws, int B, int D, int H, int W);
+void persistent3d_geo(int B, int D, int H, int W, int n_iter, int* info);   // (test-hook library)
 // C value channels per volume that share the gates ([B][C][V] value tensors, [B][26][V] gates used as given)
 bool persistent3d_multi_supported(int B, int C, int D, int H, int W, int n_iter);
 int persistent3d_forward_multi(const float* gate, const float* feat, float* out, int B, int C, int D, int H, int W, int n_iter, void* ws,

@@ -67,16 +67,24 @@ int cspn_debug_forward2d_plan(const float* guidance, const float* blur, const fl
     return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream, true, plan_mode);
 }
 
+// the plan of a persistent 3D launch: info[9] = tz, ty, cx, tiles, workgroups launched, bz, by, bx (block of the XCD-aware placement; 0: off), chunks
+int cspn_debug_3d_geo(int B, int D, int H, int W, int n_iter, int* info) {
+    persistent3d_geo(B, D, H, W, n_iter, info);
+    return 0;
+}
+
 // error word of the last persistent 3D run in this workspace (0 ok, 2 neighbour-quad timeout); synchronises
 int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) { return persistent3d_error_word(ws, B, D, H, W); }
 
-// the Paddle-contract persistent launch with workgroup `mute` never publishing its boundary (-1: nobody), coop != 0: cooperative launch
+// the Paddle-contract persistent launch with tile `mute` never publishing its boundary (-1: nobody); coop bit 0: cooperative launch,
+// bit 1: tiles in plain workgroup order instead of the XCD-aware placement (A/B)
 int cspn_debug_3d_persistent_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, int mute,
                                      int coop, void* ws, void* stream) {
     if (!persistent3d_supported(B, D, H, W, n_iter)) return CSPN_E_UNSUPPORTED;
     P3Options opt;
     opt.mute = mute;
-    opt.coop = coop != 0;
+    opt.coop = (coop & 1) != 0;
+    opt.placement = (coop & 2) == 0;
     return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, (hipStream_t)stream, opt);
 }
 
