@@ -376,7 +376,7 @@ def pmc_traffic(key):
 def roofline2d(m):
     """the `roofline` object of one timed 2D forward leg (40 / 44 B per pixel once per forward)"""
     W, n_iter, algo_name = m["W"], m["n_iter"], m["algo_name"]
-    traffic, source = pmc_traffic("%s_B%d_%s" % (m["workload"], m["B"], algo_name))
+    traffic, source = pmc_traffic("%s_B%d_%s%s" % (m["workload"], m["B"], algo_name, "_" + m["layout"] if m.get("layout") not in (None, "planar") else ""))
     r = {
         "bound": "hbm",
         "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
