@@ -40,6 +40,7 @@ WORKLOADS = {
     "kitti": (304, 1216, 24, False, 80.0, "BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216"),
     "kitti_sparse": (304, 1216, 24, True, 80.0, "BASELINE config 4: 2D CSPN 3x3 + sparse-depth replacement (500-pt mask), 24 iters, 304x1216"),
     "nyu": (228, 304, 24, True, 10.0, "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304"),
+    "plumbing": (228, 304, 12, False, 10.0, "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)"),
 }
 
 
@@ -513,6 +514,11 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
     fwd2d("config4_kitti_sparse_B32", "kitti_sparse", 32)
     fwd2d("config2_nyu_B16", "nyu", 16)
     fwd2d("config3_as_written_share_B8", "kitti", 8)
+    # config 1 is the reference's own CPU-runnable case: the engine on that shape (12 iterations: the compiler-generated kernel, the
+    # assembly loop takes passes of 24) with the reference's op sequence on the host cores beside it
+    fwd2d("config1_plumbing_B1", "plumbing", 1)
+    if "error" not in out["config1_plumbing_B1"] and not a.no_cpu_baseline:
+        out["config1_plumbing_B1"]["cpu_reference_op_sequence"] = reference_op_sequence_cpu(228, 304, 12, False, 10.0, a.norm_type, os.cpu_count() or 1, budget_s=8.0)
     try:
         out["config5_vol3d_B4"] = measure_vol3d(a, lib, _lib, dev, None, 1, 0, False, 4, 2, min(steps, 60), min(warmup, 20), pre)
     except Exception as ex:   # noqa: BLE001

@@ -22,6 +22,7 @@
 
 #include "cspn_common.h"
 
+// P3_ROWS_PLAIN / P3_NO_PRIO: A/B builds of the round-5 row assignment (correct results, tools/r05/build_p3var.sh)
 #if (defined(P3_EXP_NOPOLL) || defined(P3_EXP_NOWAIT) || defined(P3_EXP_LANE_REMAP) || defined(P3_EXP_NT) || defined(P3_PRESLEEP)) && \
     !defined(P3_EXPERIMENT_BUILD)
 #error "P3_EXP_* switch timing variants that give WRONG RESULTS: tools/build_p3var.sh defines P3_EXPERIMENT_BUILD for them"
@@ -88,6 +89,27 @@ __device__ __forceinline__ void st16_l2(float* p, float4 v) {   // no scope bits
 constexpr int QROW = 3 * XG, NROWS = TZ * TY, NQA = NROWS * QROW, NQ = NQA + 2 * NROWS;   // 1536 + 128 quads per tile and level parity
 // what a tile fetches per step: 36 halo rows (above / below / beside in y) of 24 quads, and the 200 voxels beside it in x
 constexpr int NHROW = 2 * LY + 2 * TZ, NHQ = NHROW * QROW, NSGL = 2 * LZ * LY, NIT = NHQ + NSGL, NSLOT = (NIT + NTP - 1) / NTP;
+
+// Which row of the tile a thread owns (round 5).  The 28 boundary rows of the 8 x 8 rows of a tile -- the ones whose values travel to
+// other tiles -- come FIRST: rows 0..7 plane lz = 0, 8..15 plane lz = TZ - 1, 16..27 the rows ly = 0 / TY - 1 of the planes between,
+// 28..63 the 36 interior rows.  A wave owns 8 consecutive rows, so waves 0..3 (one per SIMD) hold every boundary row; they run
+// their arithmetic at raised priority, publish ~1 000 cycles earlier than a wave that shares its SIMD evenly, and the interior
+// waves' arithmetic then runs under the publications' trip through the memory side instead of in front of it.  [q3][row][xg] in the
+// exchange buffers is indexed by the LOGICAL row lz * TY + ly as before: readers see no difference.  #define P3_ROWS_PLAIN restores
+// the round-2..4 assignment (a wave = one z plane) for A/B timing.
+__device__ __forceinline__ void row_of(int t, int& lx, int& ly, int& lz) {
+    lx = (t & (XG - 1)) * 8;
+    const int r = t >> XGS;   // 0 .. 63
+#ifdef P3_ROWS_PLAIN
+    ly = r & 7;
+    lz = r >> 3;
+#else
+    const int i = r - 16, j = r - 28, j6 = (j * 43) >> 8;   // j / 6 for 0 <= j < 36
+    lz = r < 8 ? 0 : r < 16 ? TZ - 1 : r < 28 ? 1 + (i >> 1) : 1 + j6;
+    ly = r < 8 ? r : r < 16 ? r - 8 : r < 28 ? (i & 1) * (TY - 1) : 1 + j - 6 * j6;
+#endif
+}
+static_assert(TZ == 8 && TY == 8, "row_of enumerates the boundary rows of an 8 x 8 tile cross-section");
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {   // byte address inside the workgroup's LDS
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
@@ -187,7 +209,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto gate_offs = [&](int cc, int tc, unsigned& v0, unsigned& v1) {
         const int x0n = cc * g.S - g.halo + ix * TX;
         const int bfn = __builtin_amdgcn_readfirstlane(x0n > 0 ? x0n / g.pitch : 0);
-        const int lxn = (tc & (XG - 1)) * 8, lyn = (tc >> XGS) & 7, lzn = tc >> (XGS + 3);
+        int lxn, lyn, lzn;
+        row_of(tc, lxn, lyn, lzn);
         const int zn = iz * TZ + lzn, yn = iy * TY + lyn;
         const int xr0 = x0n + lxn - bfn * g.pitch, xr1 = xr0 + 4;
         const int bq0 = bfn + (xr0 >= g.pitch ? 1 : 0), xq0n = xr0 >= g.pitch ? xr0 - g.pitch : xr0;
@@ -289,7 +312,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr int NSHT = (NSH + NTP - 1) / NTP;
                 int tc = tid;   // opaque per chunk: nothing below may be hoisted out of the chunk loop (it would be spilled, and a
                 asm volatile("" : "+v"(tc));   // spill reload waits for every load in flight)
-                const int lx = (tc & (XG - 1)) * 8, ly = (tc >> XGS) & 7, lz = tc >> (XGS + 3);
+                int lx, ly, lz;
+                row_of(tc, lx, ly, lz);
                 const int z = z0 + lz, y = y0 + ly;
                 int b0, xq0, b1, xq1;     // the thread's two quads: volume and first column
                 loc(x0 + lx, b0, xq0);
@@ -391,7 +415,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int j = 0; j < NSHT; ++j) asm volatile("" : "+v"(fs[j]));
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
-                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
+                    int lx, ly, lz;
+                    row_of(tid_, lx, ly, lz);
                     const int z = z0 + lz, y = y0 + ly;
                     int b0, xq0, b1, xq1;
                     loc(x0 + lx, b0, xq0);
@@ -458,7 +483,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float* fb = feat + (size_t)ch * V;
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
-                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
+                    int lx, ly, lz;
+                    row_of(tid_, lx, ly, lz);
                     const int z = z0 + lz, y = y0 + ly;
                     int b0, xq0, b1, xq1;
                     loc(x0 + lx, b0, xq0);
@@ -495,7 +521,8 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // tid_ each step (a handful of integer instructions) instead of being kept live across the loop
                     int tid_ = tid;
                     asm volatile("" : "+v"(tid_));
-                    const int lx = (tid_ & (XG - 1)) * 8, ly = (tid_ >> XGS) & 7, lz = tid_ >> (XGS + 3);
+                    int lx, ly, lz;
+                    row_of(tid_, lx, ly, lz);
                     const float* cur = lds + ((it - 1) & 1) * LTILE;
                     float* nxt = lds + (it & 1) * LTILE;
                     P3_STAMP(0);
@@ -503,6 +530,11 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
                         for (int k = it - 1; k < NPRE / 2; k += g.n_iter) park_gate(c + 1, k, tid_);
                     }
+#if !defined(P3_ROWS_PLAIN) && !defined(P3_NO_PRIO)
+                    // waves 0..3 own the boundary rows (row_of): their arithmetic goes first on their SIMDs, so that what other
+                    // tiles wait for is on its way while the interior waves (4..7, one on each SIMD) are still computing
+                    if (__builtin_amdgcn_readfirstlane(tid_) < 4 * 64) __builtin_amdgcn_s_setprio(3);
+#endif
                     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (HASC) {
                         const unsigned ca = lds_addr(s_c) + (unsigned)tid_ * 16u;
@@ -555,6 +587,9 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     };
                     if (it == g.n_iter) {
                         store_owned(MULTI ? out + (size_t)ch * V : out);
+#if !defined(P3_ROWS_PLAIN) && !defined(P3_NO_PRIO)
+                        __builtin_amdgcn_s_setprio(0);
+#endif
                         break;
                     }
                     float* own = nxt + ((lz + 1) * LY + (ly + 1)) * LX + lx + 1;
@@ -600,6 +635,9 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 else st16_sc1(q, make_float4(acc[7], 0.f, 0.f, tagf));
                             }
                         }
+#if !defined(P3_ROWS_PLAIN) && !defined(P3_NO_PRIO)
+                        __builtin_amdgcn_s_setprio(0);   // published: the polls below are mostly waiting
+#endif
                         // ---- the halo shell: 36 rows of the neighbours above / below / beside in y (24 quads each) and the 200 voxels
                         // beside the tile in x (one value of a neighbour's first or last quad), polled until their tag is this step's
                         unsigned src[NSLOT];   // byte offset of the quad in X
