@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """tools/tsw_cost_model.py -- time model of the fused 2D forward (time-skewed wave ring, cspn2d_tsw.hip) and what it says about
-other decompositions.  Prints profiles/r04_decomposition_model.md.
+other decompositions.  Prints profiles/r05_decomposition_model.md (round 4's table + the short-stream section of round 5).
 
-    python -m tools.tsw_cost_model > profiles/r04_decomposition_model.md
+    python -m tools.tsw_cost_model > profiles/r05_decomposition_model.md
 
 Model (every constant measured on MI355X, sources in the table the script prints):
     forward time = S x (I x c_instr + c_sync) / f
@@ -116,7 +116,7 @@ def main():
         "same instructions per SIMD and three steps either way", "0.2769-0.2786")
     row("floor of this ring: only the chain (64 v_pk_fma_f32 + 12 DPP moves per wave-step), cooking / events / feed free", S_new, chain,
         "what no pipeline around the ring can beat")
-    print("# r04 — time model of the fused 2D forward and what it says about other decompositions\n")
+    print("# r05 — time model of the fused 2D forward and what it says about other decompositions (round 4's table, constants unchanged; + short streams)\n")
     print("Generated by `python -m tools.tsw_cost_model` (the model and the sources of its constants are in that file's header).  BASELINE config 3 at")
     print("64 images per GPU (KITTI 304x1216, 24 iterations, 946.3 MB algorithmic), MI355X.\n")
     print("`forward time = S x (I x %.1f + %d) cycles / %.2f GHz`, S = steps of the longest workgroup, I = instructions a SIMD issues per step (two" % (C_INSTR, C_SYNC, F_GHZ))
@@ -143,6 +143,45 @@ def main():
     print("  coefficient through registers or LDS once (both feeds built so far, loads into VGPRs and LDS-DMA row slots, land within 1 % of each other).")
     print("* Statement the round-3 review asked for: **this design tops out at ~0.43-0.45 of the 8 TB/s roofline (0.56 of the 6.3 TB/s copy ceiling) on")
     print("  MI355X; 0.48 would take a third fewer non-chain instructions, 0.60 is out of reach.  No further rounds go into the 2D forward's pipeline**; the remaining 3 % (events) is noted above.")
+    print("* Round 5 counters (profiles/r05_pmc_sq.md): a VALU instruction holds the pipe 4.03 cycles and the pipe is busy 51 % of the kernel; the `x 5 + 260` of the fit is")
+    print("  issue turnaround plus the two waves of a SIMD waiting at the same time, i.e. schedule, not pipe occupancy.  Removing ~30 of the ~81 cooking instructions (the")
+    print("  pre-normalised input contract, profiles/r05_prenorm_ab.md) bought 2.9 %, not the 12 % an instruction count would give: the cooking math already runs under the")
+    print("  boundary rows' LDS round trip.")
+    short_streams()
+
+
+def short_streams():
+    """round 5, review item 4: an XCD-resident plan for short streams (config 3 as written = 8 images per GPU), modelled before building"""
+    hop_same, hop_cross = 0.46, 0.80       # us per hop of a tagged 16-byte quad, loaded fabric (profiles/r05_ubench_xcd_handoff.txt)
+    H, W, NI = 304, 1216, 24
+    px_cu = H * W / 32.0                   # one image per XCD, 32 CUs each own a 304 x 38-column slab
+    fma_cycles = px_cu * 8 / 2 / 64 / 4 * 4.03       # packed FMAs per SIMD x 4.03 pipe cycles (r05_pmc_sq.md)
+    lds_cycles = px_cu * (9 * 4 + 4) / 256.0          # the 3D kernel's way of holding H: 9 LDS reads + 1 write per pixel-iteration at 256 B/clk
+    comp_us = max(fma_cycles, lds_cycles) / 2150.0 * 1.6   # x1.6: what the 3D kernel's arithmetic phase takes over its LDS floor (2 000 vs 1 250 cycles)
+    sync_us = 0.25                          # polls of the second edge + LDS + barrier (3D kernel: ~1 200 cycles per step for 26 neighbours; 2 here)
+    it_us = comp_us + hop_same + sync_us
+    load_us = H * W * 40 / 0.6e12 * 1e6     # one XCD streams its image alone: 1/8 of the ~4.8 TB/s the ring's loads reach chip-wide
+    total = load_us + NI * it_us
+    alg = 8 * H * W * 40
+    print()
+    print("## Short streams: config 3 as written is 8 images per GPU (0.0645 ms = 0.229 today) -- an XCD-resident plan, modelled\n")
+    print("Idea (round-4 review): 8 images = 8 XCDs; the 32 CUs of an XCD each own a fixed 304 x 38-column slab of ONE image, its 9 coefficients per pixel")
+    print("resident in registers for all 24 iterations (%.0f pixels x 9 x 4 B = %.0f KB of a CU's 512 KB), no warm-up rows, no drain; the two edge columns of a slab" % (px_cu, px_cu * 36 / 1024))
+    print("travel to the neighbouring CUs through that XCD's L2 once per iteration, as tagged quads (the scheme of cspn3d_persistent.hip).\n")
+    print("| term | value | source |")
+    print("|---|---|---|")
+    print("| hand-off inside an XCD, per hop | %.2f us (cross-XCD %.2f) | `profiles/r05_ubench_xcd_handoff.txt`: tagged 16-byte quad, plain store + `sc1` poll, 128 pairs at once |" % (hop_same, hop_cross))
+    print("| arithmetic of one iteration on a slab | %.2f us | %.0f pixels x 8 FMA: %.0f pipe cycles per SIMD packed; LDS floor %.0f cycles (9 reads + 1 write of H per pixel at 256 B/clk); x 1.6 as measured on the 3D kernel's arithmetic phase |" % (comp_us, px_cu, fma_cycles, lds_cycles))
+    print("| polls of the second edge, LDS, barrier | %.2f us | the 3D kernel spends ~1 200 cycles per step on 26 neighbours; 2 here |" % sync_us)
+    print("| **one iteration** | **%.2f us** | a Jacobi step: nothing of iteration t + 1 can start on a slab's edge columns before the neighbour's iteration t arrived |" % it_us)
+    print("| load phase | %.1f us | 14.8 MB per image through ONE XCD's share of the fabric (~0.6 TB/s); not overlapped: every coefficient is needed before iteration 1 ends |" % load_us)
+    print("| **forward, 8 images** | **%.1f us = %.3f of the roofline** | today %.1f us = 0.229 |" % (total, alg / (total * 1e-6) / 8e12, 64.5))
+    print()
+    print("**No-go.**  The review's bar was <= 45 us (0.33); the model says %.0f us: 24 dependent hand-offs cannot be hidden (the same wall the 3D kernel stands at: its step is the" % total)
+    print("hand-off, not its arithmetic, profiles/r05_vol3d_rows_first_ab.md), and a single XCD loads its image at an eighth of the chip's bandwidth.  That is %s than today's" % ("SLOWER" if total > 64.5 else "%.0f %% faster" % (100 * (1 - total / 64.5))))
+    print("%.1f us, for a third kernel family (slab plan, edge exchange, its own cooking) that would serve one shape -- config 2 (NYU x 16: 16 images of 228 x 304 on 8 XCDs) fits it" % 64.5)
+    print("worse (two images per XCD: 16 CUs per image, 19-column slabs, the same 24 hops).  What the short-stream shapes need is fewer fixed steps per stream, which the ring cannot")
+    print("give (48 warm-up rows and a 24-step drain are its 24 levels), or more images per GPU, which is what the weak-scaling line measures (64 per GPU: 0.42).")
 
 
 if __name__ == "__main__":
