@@ -122,6 +122,14 @@ def test_bench_reductions_survive_a_failing_collective():
 
     notes = []
     assert bench._reduce(BrokenDist, [1.5, 2.5], BrokenDist.ReduceOp.MAX, "cpu", True, notes) == [1.5, 2.5]
+    assert len(notes) == 1 and "all_reduce failed" in notes[0] and "simulated" in notes[0] and bench._COLLECTIVES_BROKEN[0]
+    # round 5 (ADVICE): after the first failing collective NO further one is attempted -- a rank that carried on alone would leave
+    # the others blocked in the next collective until the RCCL timeout; the line then says "reduced": false
     bench._barrier(BrokenDist, notes)
-    assert len(notes) == 2 and "all_reduce failed" in notes[0] and "simulated" in notes[0] and "barrier failed" in notes[1]
+    assert bench._reduce(BrokenDist, [4.0], BrokenDist.ReduceOp.MAX, "cpu", True, notes) == [4.0]
+    assert len(notes) == 1
+    bench._COLLECTIVES_BROKEN[0] = False
+    bench._barrier(BrokenDist, notes)
+    assert len(notes) == 2 and "barrier failed" in notes[1] and bench._COLLECTIVES_BROKEN[0]
+    bench._COLLECTIVES_BROKEN[0] = False
     assert bench._reduce(None, [3.0], None, "cpu", True, notes) == [3.0] and len(notes) == 2   # single process: no collective at all

@@ -123,15 +123,16 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
 
 
 def test_generated_include_is_current_and_hazard_free(tmp_path, monkeypatch):
-    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 19 variants (12 forward, 6 history, the
-    adjoint sweep) -- and every one of them passes the static hazard rules (K.build raises on a hazard)"""
+    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 23 variants (16 forward: 4 norms incl. round 5's
+    prenorm x mask x continuation pass, 6 history, the adjoint sweep) -- and every one of them passes the static hazard rules (K.build
+    raises on a hazard)"""
     from tools.tswgen import emit
     out = tmp_path / "gen.inc"
     monkeypatch.setattr(sys, "argv", ["emit", str(out)])
     emit.main()
     new = out.read_text()
     old = open(os.path.join(ROOT, "cspn_amd", "csrc", "cspn2d_tsw_gen.inc")).read()
-    assert new.count("#define TSW_ASM_") == 19
+    assert new.count("#define TSW_ASM_") == 23
     assert new == old, "cspn_amd/csrc/cspn2d_tsw_gen.inc is stale: python -m tools.tswgen.emit"
 
 

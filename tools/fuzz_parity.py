@@ -1,5 +1,6 @@
 """tools/fuzz_parity.py -- random shapes: every fused path against its one-launch-per-step twin on the GPU (and the oracle on
-the small ones).  2D: the assembly ring loop vs fold + 24 step launches; 3D: persistent (plain, folded, transposed) vs per-step."""
+the small ones).  2D: the assembly ring loop vs fold + 24 step launches, the pre-normalised contract vs the raw one; 3D: persistent (plain,
+folded, transposed, C channels on shared gates forward + backward) vs per-step / per-channel."""
 import os, sys, random
 import numpy as np
 import torch
@@ -53,6 +54,16 @@ def run(cases=40, seed=1, verbose=True):
           r = cspn2d_oracle(g.cpu(), h.cpu(), None if s is None else s.cpu(), N, norm)
           e2 = float(np.nanmax(np.abs(a.cpu().numpy() - r)) / np.nanmax(np.abs(r)))
           assert e2 <= 1e-4, ("2D oracle", B, H, W, norm, sp, N, e2)
+      if norm != "none":
+          # round 5: the same call through the pre-normalised contract (cspn2d_normalize_f32 -> norm 'prenorm'): v_rcp x multiply vs an IEEE
+          # division is the only difference
+          wb = cspn_amd.cspn2d_normalize(g, norm)
+          for algo in ("auto", "stepwise"):
+              p_ = cspn_amd.cspn2d_forward(wb, h, s, N, "prenorm", algo)
+              assert torch.equal(torch.isnan(p_), torch.isnan(b)), ("2D prenorm nan", algo, B, H, W, norm, sp, N)
+              errp = float(((p_ - b).abs().nan_to_num()).max() / b.abs().nan_to_num().max().clamp_min(1e-30))
+              worst2 = max(worst2, errp)
+              assert errp <= 1e-5, ("2D prenorm", algo, B, H, W, norm, sp, N, errp)
       n2 += 1
       if N == 24 and norm != "none" and B * H * W <= 600000:
           # the backward of the same call (assembly sweeps + the recomputing final pass) against torch autograd through the plain-torch
@@ -95,6 +106,20 @@ def run(cases=40, seed=1, verbose=True):
               ef = float(np.abs(gf.cpu().numpy() - dF).max() / max(np.abs(dF).max(), 1e-30))
               assert eg <= 2e-4 and ef <= 2e-4, ("3D bwd", B, D, H, W, N, eg, ef)
               nb += 1
+          if case % 3 == 0 and B * D * H * W <= 200000:
+              # round 5: C channels on shared gates, forward and backward in one call each, against the per-channel calls
+              C = rnd.randint(2, 3)
+              x = torch.rand(B, C, D, H, W, generator=gen, device="cuda")
+              gox = torch.randn(B, C, D, H, W, generator=gen, device="cuda")
+              with torch.no_grad():
+                  fm = cspn_amd.affinity_propagate(x, g, 3, N)
+              ggm, gfm = cspn_amd.cspn3d_backward_multi(g, x, gox, N)
+              per = [cspn_amd.cspn3d_backward(g, x[:, c:c + 1].contiguous(), gox[:, c:c + 1].contiguous(), N) for c in range(C)]
+              fw = torch.cat([cspn_amd.cspn3d_forward(g, x[:, c:c + 1].contiguous(), None, N, "none") for c in range(C)], 1)
+              assert torch.equal(fm, fw), ("3D multi fwd", B, C, D, H, W, N)
+              assert torch.equal(gfm, torch.cat([p_[1] for p_ in per], 1)), ("3D multi bwd feat", B, C, D, H, W, N)
+              gs = sum(p_[0] for p_ in per)
+              assert float((ggm - gs).abs().max()) <= 1e-5 * float(gs.abs().max().clamp_min(1e-30)), ("3D multi bwd gate", B, C, D, H, W, N)
   msg = "FUZZ OK: %d 2D cases (worst fused-vs-stepwise rel diff %.3g), %d 2D backward cases vs torch autograd, %d 3D cases bit-identical, %d 3D backward cases vs oracle" % (n2, worst2, nb2, n3, nb)
   if verbose:
       print(msg)
