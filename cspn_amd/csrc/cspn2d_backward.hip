@@ -494,6 +494,202 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     else bwd_epilogue4<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
 }
 
+
+// ---- round 5: the same pass with MIXED pixel pairs (the trick of the forward ring) -----------------------------------
+// bwd_final_ck_kernel spends a third of its ~3 550 instructions per wave and tile on v_mov: a group's four pixels sit in image
+// order (c0, c1, c2, c3), so the pairs the x +- 1 taps multiply with -- (c-1, c0), (c1, c2), (c3, c+1) -- straddle the aligned
+// register pairs and are copied together for every row of every step.  Here a group lives in REGISTER order (c0, c3, c1, c2) --
+// the order the sweeps store their checkpoints in anyway --, X = (c0, c3), Y = (c1, c2), D = (c3 of the lane before, c0 of the lane
+// after: two DPP moves), and every packed FMA combines the dx = +1 tap of its low pixel with the dx = -1 tap of its high pixel:
+//   X += (w_+(c0), w_-(c3)) * Y      X += (w_-(c0), w_+(c3)) * D      X += (w_0(c0), w_0(c3)) * X
+//   Y += (w_-(c1), w_+(c2)) * X      Y += (w_0(c1), w_0(c2)) * Y      Ysw += (w_-(c2), w_+(c1)) * Y   (Y += swap(Ysw) once per step)
+// per row of taps (w_+, w_0, w_- = the row's dx = +1, 0, -1 coefficients), with the coefficient pairs mixed ONCE per tile.  The same
+// pairs serve the adjoint step in push form (products with A instead of H; what leaves for the next lane goes through the same two
+// DPP moves) and the gradient accumulators dW', which stay mixed until the epilogue.  No operand is ever copied: an H step with its 16
+// products is 32 v_pk_fma_f32 + 6 DPP + 3 swaps, an adjoint step 16 packed multiplies / FMAs + 6 DPP + 1 swap.  Same arithmetic per
+// pixel as bwd_final_ck_kernel up to the order of the nine terms of a sum.
+__device__ __forceinline__ float4 img_to_reg(float4 q) { return make_float4(q.x, q.w, q.y, q.z); }   // (c0..c3) -> (c0,c3,c1,c2)
+__device__ __forceinline__ v2f swp2(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
+
+template <int CK_ROWS>
+__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_final_mx_kernel(
+    const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
+    const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
+    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
+    constexpr int N = 24, NSEG = N / CK, CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    __shared__ __attribute__((aligned(16))) float4 sH[2][CK_NT];       // H_{s+l} of the region, two planes alternating (REGISTER order inside a quad)
+    __shared__ __attribute__((aligned(16))) float4 sA[CK][CK_NT];      // A_{s+1} .. A_{s+4}: every thread's own group only
+    __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
+    const int tid = threadIdx.x, gx = tid & (CK_GR - 1), ry = tid >> 4;
+    const int W4 = W >> 2;
+    const int nbx = (W4 + CK_TG - 1) / CK_TG, nby = (H + CK_TR - 1) / CK_TR, ntile = nbx * nby * B, per = (ntile + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);   // XCD-aware tile order, as bwd_final_ck_kernel
+    if (tile >= ntile || (int)(blockIdx.x >> 3) >= per) return;
+    const int bx = tile % nbx, by = (tile / nbx) % nby, b = tile / (nbx * nby);
+    const int y = by * CK_TR - CK + ry, xg = bx * CK_TG - 1 + gx;
+    const bool inimg = y >= 0 && y < H && xg >= 0 && xg < W4;
+    const bool intile = inimg && ry >= CK && ry < CK_ROWS - CK && gx >= 1 && gx < CK_GR - 1;
+    const int x = 4 * (inimg ? xg : 0);
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t idx = (size_t)b * HW + (size_t)(inimg ? y : 0) * W + x;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](const float* p) {
+        typedef float v4g __attribute__((ext_vector_type(4)));
+        const v4g v = *(const __attribute__((address_space(1))) v4g*)(p + idx);   // one global_load_dwordx4
+        return inimg ? make_float4(v.x, v.y, v.z, v.w) : z4;
+    };
+    // coefficient pairs, mixed once per tile.  Row of taps d = 0 (dy = +1: k = 0, 1, 2), 1 (dy = 0: k = 3, 4), 2 (dy = -1: k = 5, 6, 7);
+    // in a row: w_+ = the dx = +1 tap, w_0 = dx = 0, w_- = dx = -1
+    v2f mAX[3], mBX[3], mAYs[3], mBY[3], n0X[3], n0Y[3], cpX, cpY;
+    {
+        const float4 h0 = ld(blur);
+        float4 wq[8];
+        float sw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wq[k] = ld(wf + (size_t)k * total);
+            sw[0] += wq[k].x; sw[1] += wq[k].y; sw[2] += wq[k].z; sw[3] += wq[k].w;
+        }
+        constexpr int KP[3] = {0, 3, 5}, K0[3] = {1, 1, 6}, KM[3] = {2, 4, 7};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mAX[d] = v2f{wq[KP[d]].x, wq[KM[d]].w};    // (w_+(c0), w_-(c3))
+            mBX[d] = v2f{wq[KM[d]].x, wq[KP[d]].w};    // (w_-(c0), w_+(c3))
+            mAYs[d] = v2f{wq[KM[d]].z, wq[KP[d]].y};   // (w_-(c2), w_+(c1))
+            mBY[d] = v2f{wq[KM[d]].y, wq[KP[d]].z};    // (w_-(c1), w_+(c2))
+            n0X[d] = d == 1 ? v2f{0.f, 0.f} : v2f{wq[K0[d]].x, wq[K0[d]].w};
+            n0Y[d] = d == 1 ? v2f{0.f, 0.f} : v2f{wq[K0[d]].y, wq[K0[d]].z};
+        }
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sparse) { const float4 sq = ld(sparse); m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w); }
+        const float h0a[4] = {h0.x, h0.y, h0.z, h0.w};
+        float c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = inimg ? (norm == CSPN_NORM_NONE ? m[i] * h0a[i] : h0a[i] * (1.f - sw[i])) : 0.f;
+        cpX = v2f{c[0], c[3]}; cpY = v2f{c[1], c[2]};
+    }
+    const v2f zero2 = {0.f, 0.f};
+    v2f dAX[3], dBX[3], dAYs[3], dBY[3], dN0X[3], dN0Y[3], dCX = zero2, dCY = zero2;   // the gradient accumulators, mixed like the coefficients
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dAX[d] = dBX[d] = dAYs[d] = dBY[d] = dN0X[d] = dN0Y[d] = zero2;
+    const int tdn_i = ry < CK_ROWS - 1 ? tid + CK_GR : tid, tup_i = ry > 0 ? tid - CK_GR : tid;
+    auto seg_h = [&](int j) { return ld(j == 0 ? blur : hh + (size_t)(j - 1) * total); };                       // H_{4j}
+    auto seg_a = [&](int j) { return ld(j == NSEG - 1 ? gout : ah + (size_t)(NSEG - 2 - j) * total); };         // A_{4j+4}
+    const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;
+    float4 nh = seg_h(0), na = seg_a(0);   // the checkpoints are requested one segment ahead
+    int par = 0;
+    auto segments = [&](auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+#pragma unroll 1
+        for (int j = 0; j < NSEG; ++j) {
+            // (the sweeps' planes are in register order already; blur / dL/dout are in image order)
+            float4 hq = j == 0 ? img_to_reg(nh) : nh;
+            const float4 aq4 = j == NSEG - 1 ? img_to_reg(na) : na;
+            if (j + 1 < NSEG) { nh = seg_h(j + 1); na = seg_a(j + 1); }
+            // ---- the adjoint levels first: A_{s+4} -> A_{s+3}, A_{s+2}, A_{s+1} (push form), each parked in the thread's own LDS slot
+            v2f aX = v2f{aq4.x, aq4.y}, aY = v2f{aq4.z, aq4.w};
+            sA[CK - 1][tid] = aq4;
+#pragma unroll 1
+            for (int l = CK - 1; l >= 1; --l) {
+                const v2f aYs = swp2(aY);
+                v2f tX[3], tY[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const v2f M = mBX[d] * aX;                                   // (P_-(c0), P_+(c3)): what leaves for the neighbouring lanes
+                    tX[d] = v2f{dpp_shr1(M[1]), dpp_shl1(M[0])};                 // (P_+(c3 of the lane before), P_-(c0 of the lane after))
+                    tX[d] = __builtin_elementwise_fma(mBY[d], aY, tX[d]);        // + (P_-(c1), P_+(c2))
+                    tY[d] = mAX[d] * aX;                                         // (P_+(c0), P_-(c3))
+                    tY[d] = __builtin_elementwise_fma(mAYs[d], aYs, tY[d]);      // + (P_-(c2), P_+(c1))
+                    if (d != 1) {
+                        tX[d] = __builtin_elementwise_fma(n0X[d], aX, tX[d]);
+                        tY[d] = __builtin_elementwise_fma(n0Y[d], aY, tY[d]);
+                    }
+                }
+                sT[par][0][tid] = make_float4(tX[0][0], tX[0][1], tY[0][0], tY[0][1]);   // dy = +1: to the row below
+                sT[par][1][tid] = make_float4(tX[2][0], tX[2][1], tY[2][0], tY[2][1]);   // dy = -1: to the row above
+                lds_barrier();
+                const float4 fa = sT[par][0][tup_i];     // from the row above, sent down
+                const float4 fb = sT[par][1][tdn_i];     // from the row below, sent up
+                par ^= 1;
+                aX = tX[1] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y};
+                aY = tY[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w};
+                if (MASKED && !inimg) { aX = zero2; aY = zero2; }
+                sA[l - 1][tid] = make_float4(aX[0], aX[1], aY[0], aY[1]);
+            }
+            // ---- then H_s -> H_{s+3}; the row pairs of a step are also what A_{t+1} multiplies with for dW'
+            sH[0][tid] = hq;
+            lds_barrier();
+#pragma unroll 1
+            for (int l = 0; l < CK; ++l) {
+                const float4 q[3] = {sH[l & 1][tdn_i], hq, sH[l & 1][tup_i]};   // rows y + 1, y, y - 1 (at the region's first / last row: the own row again, halo)
+                v2f Xr[3], Yr[3], Dr[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    Xr[d] = v2f{q[d].x, q[d].y};
+                    Yr[d] = v2f{q[d].z, q[d].w};
+                    Dr[d] = v2f{dpp_shr1(q[d].y), dpp_shl1(q[d].x)};   // (c3 of the lane before, c0 of the lane after; 0 at the region's edge: halo)
+                }
+                if (wave_in_tile_rows) {
+                    const float4 aq = sA[l][tid];   // A_{s+l+1}
+                    const v2f bX = v2f{aq.x, aq.y}, bY = v2f{aq.z, aq.w}, bYs = swp2(bY);
+                    dCX += bX;
+                    dCY += bY;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        dAX[d] = __builtin_elementwise_fma(bX, Yr[d], dAX[d]);
+                        dBX[d] = __builtin_elementwise_fma(bX, Dr[d], dBX[d]);
+                        dBY[d] = __builtin_elementwise_fma(bY, Xr[d], dBY[d]);
+                        dAYs[d] = __builtin_elementwise_fma(bYs, Yr[d], dAYs[d]);
+                        if (d != 1) {
+                            dN0X[d] = __builtin_elementwise_fma(bX, Xr[d], dN0X[d]);
+                            dN0Y[d] = __builtin_elementwise_fma(bY, Yr[d], dN0Y[d]);
+                        }
+                    }
+                }
+                if (l == CK - 1) break;
+                v2f nX = cpX, nY = cpY, nYs = mAYs[0] * Yr[0];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    nX = __builtin_elementwise_fma(mAX[d], Yr[d], nX);
+                    nX = __builtin_elementwise_fma(mBX[d], Dr[d], nX);
+                    nY = __builtin_elementwise_fma(mBY[d], Xr[d], nY);
+                    if (d != 0) nYs = __builtin_elementwise_fma(mAYs[d], Yr[d], nYs);
+                    if (d != 1) {
+                        nX = __builtin_elementwise_fma(n0X[d], Xr[d], nX);
+                        nY = __builtin_elementwise_fma(n0Y[d], Yr[d], nY);
+                    }
+                }
+                nY += swp2(nYs);
+                if (MASKED && !inimg) { nX = zero2; nY = zero2; }
+                hq = make_float4(nX[0], nX[1], nY[0], nY[1]);
+                sH[(l + 1) & 1][tid] = hq;   // (the plane read two steps ago: everybody is past the barrier in between)
+                lds_barrier();
+            }
+        }
+    };
+    const int ry0 = by * CK_TR - CK, xg0 = bx * CK_TG - 1;
+    const bool blk_in = ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4;
+    if (blk_in) segments(std::false_type{});
+    else segments(std::true_type{});
+    if (!intile) return;
+    // un-mix: dW'_k per pixel in image order, as the epilogue wants it
+    float dWs[8][4], dCs[4] = {dCX[0], dCY[0], dCY[1], dCX[1]};
+    constexpr int KP[3] = {0, 3, 5}, K0[3] = {1, 1, 6}, KM[3] = {2, 4, 7};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        dWs[KP[d]][0] = dAX[d][0];  dWs[KM[d]][3] = dAX[d][1];
+        dWs[KM[d]][0] = dBX[d][0];  dWs[KP[d]][3] = dBX[d][1];
+        dWs[KM[d]][2] = dAYs[d][0]; dWs[KP[d]][1] = dAYs[d][1];
+        dWs[KM[d]][1] = dBY[d][0];  dWs[KP[d]][2] = dBY[d][1];
+        if (d != 1) {
+            dWs[K0[d]][0] = dN0X[d][0]; dWs[K0[d]][3] = dN0X[d][1];
+            dWs[K0[d]][1] = dN0Y[d][0]; dWs[K0[d]][2] = dN0Y[d][1];
+        }
+    }
+    if (blk_in) bwd_epilogue4<true>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+    else bwd_epilogue4<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+}
+
 }  // namespace
 
 constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
@@ -515,8 +711,13 @@ static void launch_final_ck(const float* g, const float* blur, const float* spar
                             const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
     constexpr int ROWS = 48, TROWS = ROWS - 2 * CK;
     const int ntile = ((W / 4 + CK_TG - 1) / CK_TG) * ((H + TROWS - 1) / TROWS) * B, per = (ntile + 7) / 8;
+#ifdef BWD_FINAL_CK   // (A/B build: the round-3 kernel, image-order pixel pairs)
     hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
                        gg, gb, B, H, W, norm);
+#else
+    hipLaunchKernelGGL(bwd_final_mx_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
+                       gg, gb, B, H, W, norm);
+#endif
 }
 
 int backward2d(const float* g, const float* blur, const float* sparse, const float* gout, float* gg, float* gb, int B, int H,
