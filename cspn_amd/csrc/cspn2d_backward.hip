@@ -308,7 +308,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt 0), i.e. for the next
 // segment's checkpoints that are meant to arrive under this segment's arithmetic
+#ifdef BWD_EXP_NOBAR   // (timing-only build, WRONG RESULTS: what do the 42 barriers per tile cost?)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // CK_ROWS = region rows: 48 (one block of 768 threads per CU, three waves per SIMD).  Measured alternatives
 // (profiles/r03_backward_checkpoints.md): 24 and 32 rows with two blocks per CU, 64 rows with 1024 threads -- all slower.
