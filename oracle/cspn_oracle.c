@@ -17,6 +17,11 @@
  *     unmodified reference module (tests/golden/make_golden.py, run in the
  *     authoring container) and tests/test_oracle.py checks this file against
  *     them.
+ *     'prenorm' (norm_type 3) and cspn2d_oracle_gate_wb_f32: PINNED as well --
+ *     tests/golden/cspn2d_norm_golden.npz holds gate_wb / gate_sum as the unmodified
+ *     reference's affinity_normalization returned them (tests/golden/make_norm_golden.py);
+ *     the export reproduces them and the 'prenorm' mode, fed the GOLDEN gate_wb,
+ *     reproduces the golden outputs (tests/test_oracle.py).
  *   3D and norm_type==2 (Paddle style): PARITY UNPINNED.  The arithmetic of
  *     fluid.layers.affinity_propagate lives in a custom PaddlePaddle 1.5.2
  *     wheel that is not in the reference tree (cspn_paddle/README.md:24,30-35)
