@@ -3,7 +3,7 @@
 The hardware counters say a third of the loop's LDS-active cycles are conflict cycles (profiles/r05_pmc_sq.md, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 This runs the generated loop in the CPU emulator (tools/tswgen/emu.py: per-lane LDS addresses are exact) and prices every LDS access with the lane groups and
 bank rule of MI355X_MICROARCH.md (LDS): conflict cycles = sum over lane groups of (most distinct addresses on one bank - 1).
-    python -m tools.r05.tsw_lds_conflicts [norm] [RING_REC bytes]"""
+    python -m tools.r05.tsw_lds_conflicts [norm] [RING_REC bytes] [1: ring stores as ds_write2_b32]"""
 import os
 import sys
 
@@ -57,6 +57,8 @@ def patched(self, w, addr, ndw, write, lanes, align):
 
 def main():
     norm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    if len(sys.argv) > 3:
+        K.RING_W2 = sys.argv[3] == "1"
     if len(sys.argv) > 2:
         K.RING_REC = int(sys.argv[2])
         K.RING_SLOT = 64 * K.RING_REC

@@ -22,7 +22,9 @@ PADF, PADB = 36, 48          # inactive descriptor rows before / after a workgro
 DESC_BYTES = 16              # goff_lo, goff_hi, boff, flags | lo << 8 | hi << 20
 # ring of cooked rows: 8 slots x 64 lane records; a record = [plane 0..9][column 0..3] floats + 2 pad = 42 dwords, so that the
 # cooking lanes (two per record, 8 adjacent bytes each) and the reading lanes (stride 42 dwords) are free of bank conflicts
-RING_REC = 168
+import os as _os
+RING_REC = int(_os.environ.get("TSW_RING_REC", "168"))   # (experiment builds: tools/r05/build_ringrec.sh -- 168 is the product's)
+RING_W2 = _os.environ.get("TSW_RING_W2", "0") == "1"      # ring stores as ds_write2_b32 (4-byte aligned): allows an odd dword stride, e.g. 172 bytes
 LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 64 * RING_REC
 # cfg elastic: no barrier in the loop -- a wave tells its ring neighbours with a tag that the boundary rows of a step are in LDS
 # (mailbox of the READER: [8 waves][2 counter parities][top, bottom] dwords), and the cooking waves tag the ring slots
@@ -30,7 +32,7 @@ LDS_BND, LDS_RING, RING_SLOT = 0, 32768, 64 * RING_REC
 LDS_TAGS = LDS_RING + 8 * RING_SLOT
 TAG_RT = 128
 LDS_TAB = LDS_TAGS                   # the workgroup's row-descriptor table (written by the C++ part of the kernel)
-TAB_MAX_ROWS = 2816
+TAB_MAX_ROWS = min(2816, (163840 - LDS_TAB) // 16)
 LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES   # 160 KB
 assert LDS_BYTES <= 163840
 
@@ -42,7 +44,7 @@ def configure(tag_area):
     import os
     shift = int(os.environ.get("TSW_TAB_SHIFT", "0"))   # experiment: where the table starts (multiple of 16 bytes)
     LDS_TAB = LDS_TAGS + (256 if tag_area else 0) + shift
-    TAB_MAX_ROWS = (2800 if tag_area else 2816) - shift // 16
+    TAB_MAX_ROWS = min((2800 if tag_area else 2816) - shift // 16, (163840 - LDS_TAB) // 16)
     LDS_BYTES = LDS_TAB + TAB_MAX_ROWS * DESC_BYTES
 DY = [1, 1, 1, 0, 0, -1, -1, -1]
 DX = [1, 0, -1, 1, -1, 1, 0, -1]
@@ -776,8 +778,8 @@ class Gen(object):
             self.p.label(l_nown)
         hv = PEND_HIN if self.hin else PEND_BLUR
         if not nw:
-            self.e("ds_write_b64", (), [ringw, cc], offset=8 * 16)
-            self.e("ds_write_b64", (), [ringw, hv], offset=9 * 16)
+            self.ring_w8(ringw, cc, 8 * 16)
+            self.ring_w8(ringw, hv, 9 * 16)
         self.e("s_branch", (), [l_done])
         self.p.label(l_inact)
         self.mov(OUTQ[0], 0)
@@ -787,14 +789,25 @@ class Gen(object):
             self.mov(g[k][1], 0)
         if not nw:
             for k in (8, 9):
-                self.e("ds_write_b64", (), [ringw, OUTQ.sub(0, 2)], offset=k * 16)
+                self.ring_w8(ringw, OUTQ.sub(0, 2), k * 16)
         self.p.label(l_done)
         return deferred
+
+    def ring_w8(self, addr, reg, off, **m):
+        """8 bytes (a pixel pair) into the ring record at addr + off.  RING_W2 (round 5): as ds_write2_b32 with adjacent offsets instead of ds_write_b64 --
+        the same one instruction, but it needs 4-byte alignment only, which lets the records stand an ODD number of dwords apart: the events' one-record-
+        per-lane ds_read2_b32 then hit 32 different banks (with the even 42-dword stride they hit 16, twice each), and what 2-way conflicts the stores
+        keep is hidden under their operand transfer (MI355X_MICROARCH.md, LDS; tools/r05/tsw_lds_conflicts.py)."""
+        if RING_W2:
+            assert off % 4 == 0 and off // 4 + 1 < 256
+            self.e("ds_write2_b32", (), [addr, reg[0], reg[1]], offset0=off // 4, offset1=off // 4 + 1, **m)
+        else:
+            self.e("ds_write_b64", (), [addr, reg], offset=off, **m)
 
     def ring_writes(self, deferred, lo=None, hi=None):
         for i, (addr, reg, off) in enumerate(deferred):
             m = {} if lo is None else {"at": lo + (hi - lo) * i / max(1, len(deferred))}
-            self.e("ds_write_b64", (), [addr, reg], offset=off, **m)
+            self.ring_w8(addr, reg, off, **m)
 
     def issue_prepare(self, cd):
         """scalar side of a task request: flags and the base addresses of its rows (kept in s0..s11 while the loads are
