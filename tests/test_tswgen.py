@@ -199,3 +199,19 @@ def test_emulated_staggered_cooking_option():
     os.chdir(ROOT)
     err, nanmis, _, ref = run_case(2, 17, 304, 5, 0, True, False, seed=9, zero_patch=True, verbose=False, cfg_extra=dict(stagger=True))
     assert nanmis == 0 and err <= 1e-4 and np.isnan(ref).any()
+
+
+def test_emulated_ring_with_odd_record_stride_and_write2_stores(monkeypatch):
+    """round 5 experiment switch (TSW_RING_REC / TSW_RING_W2, profiles/r05_lds_conflicts_and_sq.md): the cooked-row ring at 41 dwords per record with
+    its 8-byte stores issued as ds_write2_b32 -- conflict-free event reads; measured +-0 on the GPU, kept as a generator option: it must stay correct"""
+    os.chdir(ROOT)
+    monkeypatch.setattr(K, "RING_REC", 164)
+    monkeypatch.setattr(K, "RING_SLOT", 64 * 164)
+    monkeypatch.setattr(K, "LDS_TAGS", K.LDS_RING + 8 * 64 * 164)
+    monkeypatch.setattr(K, "RING_W2", True)
+    try:
+        err, nanmis, _, ref = run_case(2, 17, 304, 5, 0, True, False, seed=5, zero_patch=True, verbose=False)
+        assert nanmis == 0 and err <= 1e-4 and np.isnan(ref).any()
+    finally:
+        monkeypatch.undo()
+        K.configure(False)
