@@ -42,7 +42,7 @@ WORKLOADS = {
     "nyu": (228, 304, 24, True, 10.0, "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304"),
     "plumbing": (228, 304, 12, False, 10.0, "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)"),
     # off the fast path (round-4 review, weak 8): measured for the record, not part of the driver's line
-    "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (Paddle's default propStep): the compiler-generated ring kernel, the assembly loop takes passes of 24"),
+    "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (BASELINE config 1's count; the reference's own defaults are 24, cspn_paddle/demo.py:92): the compiler-generated ring kernel, the assembly loop takes passes of 24"),
     "kitti_w1218": (304, 1218, 24, False, 80.0, "304x1218 (W % 4 != 0), 24 iterations: fold + one launch per iteration"),
 }
 
