@@ -164,7 +164,7 @@ for nthr in sorted({min(cores, 16), min(cores, 64), cores}):
 def reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, cores, budget_s=24.0):
     """tools/torch_ops_baseline.py -- the op sequence reference cspn.py:42-83 launches, pinned to the unmodified reference's golden
     vectors -- on torch-CPU, ONE image per forward, at 16 / 64 / all host threads.  Runs in a CHILD process (its own OpenMP runtime:
-    in this process the oracle's 256 spinning OpenMP threads made torch-CPU 100x slower, profiles/r05_cpu_baseline_notes.md) and is
+    in this process the oracle's 256 spinning OpenMP threads made torch-CPU 100x slower, profiles/r05_perf_notes.md) and is
     bounded: a thread count whose full forward projects beyond the leg's budget is reported as skipped with the projection."""
     import subprocess
     try:
