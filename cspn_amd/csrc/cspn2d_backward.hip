@@ -516,7 +516,7 @@ __device__ __forceinline__ float4 img_to_reg(float4 q) { return make_float4(q.x,
 __device__ __forceinline__ v2f swp2(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
 
 template <int CK_ROWS>
-__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_final_mx_kernel(
+__global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(CK_ROWS / 16, CK_ROWS / 16))) void bwd_final_mx_kernel(
     const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
     const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
     float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
@@ -713,7 +713,11 @@ size_t backward2d_workspace(int B, int H, int W, int n_iter) {
 // final pass of the assembly-sweep backward: from the checkpoints of both sweeps
 static void launch_final_ck(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* wf,
                             const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
+#ifdef BWD_FINAL_ROWS   // (A/B build: 64 = 1 024 threads, four waves per SIMD at 128 registers, all 160 KB of LDS)
+    constexpr int ROWS = BWD_FINAL_ROWS, TROWS = ROWS - 2 * CK;
+#else
     constexpr int ROWS = 48, TROWS = ROWS - 2 * CK;
+#endif
     const int ntile = ((W / 4 + CK_TG - 1) / CK_TG) * ((H + TROWS - 1) / TROWS) * B, per = (ntile + 7) / 8;
 #ifdef BWD_FINAL_CK   // (A/B build: the round-3 kernel, image-order pixel pairs)
     hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
