@@ -285,6 +285,120 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
     }
 }
 
+// The same epilogue in TWO passes over the eight guidance runs, for the 64-row final pass (round 5): the first pass only sums (S = sum |G|,
+// sum G, T1 = sum dL/dw_k G_k), the second loads each run again (it is in L2) and writes its gradient -- the runs are never all live, so the
+// kernel fits 128 registers and four waves per SIMD.  Same arithmetic, same order of the sums as bwd_epilogue4.
+template <bool INTERIOR, class GetDW>
+__device__ __attribute__((noinline)) void bwd_epilogue4_2pass(const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse,
+                                                    const float* __restrict__ a0p, float* __restrict__ gg, float* __restrict__ gb, int b, int y,
+                                                    int x, size_t idx, size_t HW, int H, int W, int norm, GetDW get_dw /* k -> dW'_k of the 4 pixels */,
+                                                    const float (&dC)[4]) {
+    const float4 h0q = *reinterpret_cast<const float4*>(blur + idx);
+    const float h0[4] = {h0q.x, h0q.y, h0q.z, h0q.w};
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sparse) {
+        const float4 sq = *reinterpret_cast<const float4*>(sparse + idx);
+        m[0] = signf(sq.x); m[1] = signf(sq.y); m[2] = signf(sq.z); m[3] = signf(sq.w);
+    }
+    const float* gbp = g + (size_t)b * 8 * HW;
+    float* ggp = gg ? gg + (size_t)b * 8 * HW : nullptr;
+    if (norm == CSPN_NORM_NONE) {  // gates used as given, centre-sited, no centre term: c' = m H_0
+        if (gb) {
+            const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
+            *reinterpret_cast<float4*>(gb + idx) = make_float4(a0q.x + dC[0] * m[0], a0q.y + dC[1] * m[1], a0q.z + dC[2] * m[2], a0q.w + dC[3] * m[3]);
+        }
+        if (ggp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 w = get_dw(k);
+                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
+                    make_float4((1.f - m[0]) * w.x, (1.f - m[1]) * w.y, (1.f - m[2]) * w.z, (1.f - m[3]) * w.w);
+            }
+        }
+        return;
+    }
+    auto run = [&](int k, float (&v)[4]) -> bool {
+        const int yy = y + dy2(k), xs = x + dx2(k);
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (!INTERIOR && (yy < 0 || yy >= H)) return false;
+        const float* src = gbp + k * HW + (size_t)yy * W;
+        if (INTERIOR || (xs >= 0 && xs + 3 < W)) {
+            const float4 q = ld4u(src + xs);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xs + i >= 0 && xs + i < W) v[i] = src[xs + i];
+        }
+        return true;
+    };
+    float om[4], ch[4], S[4] = {0.f, 0.f, 0.f, 0.f}, T1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // pass 1: a run is consumed at once
+        float v[4];
+        run(k, v);
+        const float4 wq = get_dw(k);
+        const float dWk[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+            S[i] += fabsf(v[i]);
+            gs[i] += G;
+            T1[i] = fmaf(om[i] * (dWk[i] - ch[i]), G, T1[i]);
+        }
+    }
+    float rS[4], t2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rS[i] = __builtin_amdgcn_rcpf(S[i]); t2[i] = T1[i] * rS[i] * rS[i]; }
+    if (gb) {
+        const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
+        const float a0[4] = {a0q.x, a0q.y, a0q.z, a0q.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = a0[i] + dC[i] * (om[i] * (1.f - gs[i] * rS[i]) + m[i]);
+        *reinterpret_cast<float4*>(gb + idx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (ggp) {
+        if (!INTERIOR && (y == 0 || y == H - 1 || x == 0 || x + 4 >= W)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ys = y - dy2(k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int xq = x + i - dx2(k);
+                    if (ys < 0 || ys >= H || xq < 0 || xq >= W) ggp[k * HW + (size_t)y * W + x + i] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {   // pass 2
+            float v[4];
+            if (!run(k, v)) continue;  // the zero padding is a constant
+            const int yy = y + dy2(k), xs = x + dx2(k);
+            const float4 wq = get_dw(k);
+            const float dWk[4] = {wq.x, wq.y, wq.z, wq.w};
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float G = norm == CSPN_NORM_8SUM_ABS ? fabsf(v[i]) : v[i];
+                const float sg = G > 0.f ? 1.f : (G < 0.f ? -1.f : 0.f);
+                float r = om[i] * (dWk[i] - ch[i]) * rS[i] - sg * t2[i];
+                if (norm == CSPN_NORM_8SUM_ABS) r *= v[i] > 0.f ? 1.f : (v[i] < 0.f ? -1.f : 0.f);
+                d[i] = r;
+            }
+            float* dst = ggp + k * HW + (size_t)yy * W;   // g_k(p + off_k) is read by pixel p only
+            if (INTERIOR || (xs >= 0 && xs + 3 < W)) st4u(dst + xs, make_float4(d[0], d[1], d[2], d[3]));
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xs + i >= 0 && xs + i < W) dst[xs + i] = d[i];
+            }
+        }
+    }
+}
+
 // ---- final pass from CHECKPOINTS (round 3): the sweeps keep every fourth level only ----------------------------------------
 // The forward sweep stores H_4, H_8 .. H_20, the adjoint sweep A_20, A_16 .. A_4 (generator option hist_every; H_0 = blur and
 // A_24 = dL/dout are inputs): 10 level planes through HBM instead of 46.  This pass recomputes the three levels in between,
@@ -690,8 +804,30 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
             dWs[K0[d]][1] = dN0Y[d][0]; dWs[K0[d]][2] = dN0Y[d][1];
         }
     }
-    if (blk_in) bwd_epilogue4<true>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
-    else bwd_epilogue4<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+#ifdef BWD_EXP_MX_NOEPI   // (compile-time probe, WRONG RESULTS: how many registers does the level loop need on its own?)
+    float acc = dCs[0] + dCs[1] + dCs[2] + dCs[3];
+    for (int k = 0; k < 8; ++k) acc += dWs[k][0] + dWs[k][1] + dWs[k][2] + dWs[k][3];
+    gb[idx] = acc;
+#else
+    if (CK_ROWS > 48) {
+        // four waves per SIMD = 128 registers: the 32 gradient accumulators wait in the thread's OWN LDS slots while the epilogue runs
+        // (sA is never read by anybody else; sT has not been read since the last segment's adjoint steps, a barrier ago): no barrier needed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sA[k][tid] = make_float4(dWs[k][0], dWs[k][1], dWs[k][2], dWs[k][3]);
+            sT[k >> 1][k & 1][tid] = make_float4(dWs[4 + k][0], dWs[4 + k][1], dWs[4 + k][2], dWs[4 + k][3]);
+        }
+        struct LdsDW {   // (by value into the non-inlined epilogue: the thread's eight slots)
+            const float4* a; const float4* t; int nt;
+            __device__ float4 operator()(int k) const { return k < 4 ? a[k * nt] : t[(k - 4) * nt]; }
+        } get_dw{&sA[0][tid], &sT[0][0][tid], CK_NT};
+        if (blk_in) bwd_epilogue4_2pass<true>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, get_dw, dCs);
+        else bwd_epilogue4_2pass<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, get_dw, dCs);
+    } else {
+        if (blk_in) bwd_epilogue4<true>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+        else bwd_epilogue4<false>(g, blur, sparse, a0p, gg, gb, b, y, x, idx, HW, H, W, norm, dWs, dCs);
+    }
+#endif
 }
 
 }  // namespace
