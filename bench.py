@@ -42,7 +42,7 @@ WORKLOADS = {
     "nyu": (228, 304, 24, True, 10.0, "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304"),
     "plumbing": (228, 304, 12, False, 10.0, "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)"),
     # off the fast path (round-4 review, weak 8): measured for the record, not part of the driver's line
-    "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (BASELINE config 1's count; the reference's own defaults are 24, cspn_paddle/demo.py:92): the compiler-generated ring kernel, the assembly loop takes passes of 24"),
+    "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (BASELINE config 1's count; the reference's own defaults are 24, cspn_paddle/demo.py:92): one short pass of the assembly loop (round 5: a row is stored when it completes level 12)"),
     "kitti_w1218": (304, 1218, 24, False, 80.0, "304x1218 (W % 4 != 0), 24 iterations: fold + one launch per iteration"),
 }
 
@@ -517,8 +517,8 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
     fwd2d("config4_kitti_sparse_B32", "kitti_sparse", 32)
     fwd2d("config2_nyu_B16", "nyu", 16)
     fwd2d("config3_as_written_share_B8", "kitti", 8)
-    # config 1 is the reference's own CPU-runnable case: the engine on that shape (12 iterations: the compiler-generated kernel, the
-    # assembly loop takes passes of 24) with the reference's op sequence on the host cores beside it
+    # config 1 is the reference's own CPU-runnable case: the engine on that shape (12 iterations: one short pass of the assembly loop)
+    # with the reference's op sequence on the host cores beside it
     fwd2d("config1_plumbing_B1", "plumbing", 1)
     if "error" not in out["config1_plumbing_B1"] and not a.no_cpu_baseline:
         out["config1_plumbing_B1"]["cpu_reference_op_sequence"] = reference_op_sequence_cpu(228, 304, 12, False, 10.0, a.norm_type, os.cpu_count() or 1, budget_s=8.0)

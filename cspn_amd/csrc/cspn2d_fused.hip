@@ -571,13 +571,22 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
     if (((uintptr_t)out & 15u) != 0) { set_error("fused kernel needs a 16-byte aligned output"); return CSPN_E_UNSUPPORTED; }
     const int passes = (n_iter + LV - 1) / LV;
     float* pingpong = (float*)ws;
-    const bool asm_ok = use_asm && n_iter >= LV && tsw2d_supported(B, H, W);
+    const bool asm_ok = use_asm && tsw2d_supported(B, H, W);
     const float* hin = blur;
     int done = 0;
     for (int p = 0; p < passes; ++p) {
-        const int n = (n_iter - done) < LV ? (n_iter - done) : LV;
+        // the assembly loop (round 5: every n_iter) runs the remainder n_iter % 24 FIRST -- its short pass is a first pass, the full passes
+        // continue from any level --; the compiler-generated kernel below (narrow images, experiment switches) runs it last, as before
+        const int rem = n_iter % LV;
+        const int n = asm_ok ? ((p == 0 && rem) ? rem : LV) : ((n_iter - done) < LV ? (n_iter - done) : LV);
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
+        if (asm_ok && n < LV) {
+            if (int e = tsw2d_pass(g, blur, blur, sparse, dst, B, H, W, norm, st, nullptr, plan_mode, n)) return e;
+            hin = dst;
+            done += n;
+            continue;
+        }
         if (asm_ok && n == LV) {
 #ifdef CSPN_EXPERIMENTS
             if (plan_mode == 3) {   // the round-3 loop (experiment builds only)

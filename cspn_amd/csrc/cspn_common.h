@@ -77,10 +77,11 @@ size_t fused2d_workspace(int B, int H, int W, int n_iter);
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
                     int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true, int plan_mode = 0);
 
-// ---- the same ring with the main loop in gfx950 assembly (cspn2d_tsw.hip); one pass = exactly 24 iterations ----
+// ---- the same ring with the main loop in gfx950 assembly (cspn2d_tsw.hip); one pass = 24 iterations, or -- a FIRST pass only
+// (hin == blur, no history) -- n_early = 1 .. 23 of them ----
 bool tsw2d_supported(int B, int H, int W);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
-               int W, int norm, hipStream_t st, float* hist = nullptr, int plan_mode = 0);
+               int W, int norm, hipStream_t st, float* hist = nullptr, int plan_mode = 0, int n_early = 0);
 #ifdef CSPN_EXPERIMENTS
 // ---- experiments kept out of the default build (make EXPERIMENTS=1): the round-3 loop (cspn2d_tsw3.hip: LDS-DMA row slots;
 // ties with the loop above on long streams, slower on short ones: profiles/r03_perf_notes.md) and the sited8 guidance layout ----

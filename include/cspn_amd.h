@@ -54,9 +54,10 @@ typedef void* cspn_stream_t;
 enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2,
        CSPN_NORM_PRENORM = 3 /* 2D forward only: `guidance` holds the reference's gate_wb (see cspn2d_normalize_f32 below) */ };
 
-/* algo: AUTO picks the fused single-launch kernel whenever the shape allows it.  FUSED runs every pass of exactly 24
- * iterations through the assembly main loop when the image is at least 256 columns wide; FUSED_CXX forces the
- * compiler-generated version of the same kernel (A/B tests). */
+/* algo: AUTO picks the fused kernel whenever the shape allows it (W % 4 == 0, 16-byte aligned output).  FUSED runs images at
+ * least 256 columns wide through the assembly main loop for EVERY n_iter (round 5): n_iter = 24 k + r is one short first pass
+ * of r iterations (a row is stored when it completes level r) followed by k passes of 24 -- one launch per pass, 40 / 44 B
+ * per pixel and pass; narrower images and FUSED_CXX (A/B tests) take the compiler-generated version of the same kernel. */
 enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2, CSPN_ALGO_FUSED_CXX = 3 };
 
 enum {

@@ -479,7 +479,7 @@ def test_paddle_style_affinity_propagate():
     assert rel_err(o2.cpu().numpy(), cspn2d_oracle(g2, x2, None, 4, "none")) <= RTOL
 
 
-# ---- shapes that take the assembly main loop (cspn2d_tsw.hip: W >= 256, passes of exactly 24 iterations) ----------------
+# ---- shapes that take the assembly main loop (cspn2d_tsw.hip: W >= 256; round 5: any n_iter = a short first pass + full passes) ------
 TSW_SHAPES = [
     (2, 40, 256, 24, "8sum", True),        # one band, both band-edge flags on the same band
     (1, 70, 512, 24, "8sum", False),       # two bands, the last one shifted to the image edge
@@ -487,7 +487,11 @@ TSW_SHAPES = [
     (1, 3, 260, 24, "8sum", True),         # fewer rows than iterations
     (1, 1, 256, 24, "8sum", False),        # single row: both vertical neighbours missing
     (2, 50, 300, 48, "8sum", True),        # two assembly passes chained through the ping buffer
-    (1, 64, 516, 30, "8sum_abs", True),    # 24 in assembly + 6 in the compiler-generated kernel
+    (1, 64, 516, 30, "8sum_abs", True),    # a short first pass of 6 + a full pass (round 5; fused_cxx: 24 + 6 in the compiler-generated kernel)
+    (2, 50, 300, 12, "8sum", True),        # BASELINE config 1's count: one short pass
+    (1, 40, 260, 1, "8sum", False),        # a single iteration
+    (2, 37, 304, 23, "8sum_abs", True),    # the longest short pass
+    (1, 33, 520, 59, "none", True),        # 11 + 24 + 24
     (1, 45, 1216, 24, "none", True),       # KITTI width, centre-sited pre-normalised gates
     (6, 304, 1216, 24, "8sum", True),      # full-size images, every workgroup on the device busy
 ]
@@ -504,6 +508,23 @@ def test_asm_loop_parity_vs_oracle(B, H, W, N, norm, sp):
     outs = {a: _run(g, h, s, N, norm, a) for a in ("fused", "fused_cxx", "fused_groups", "fused_noxcd")}
     for a, o in outs.items():
         assert_close_tight(o, ref, a)
+
+
+def test_asm_loop_every_iteration_count_matches_the_compiled_kernel():
+    """round 5: n_iter = 1 .. 50 all run in the assembly loop (a short first pass of n_iter % 24 iterations -- the row is stored when it
+    completes that level --, then full passes); against the compiler-generated ring kernel, which plans and retires independently, and
+    for a few counts against the oracle; NaN patch and negative-sparse points included"""
+    B, H, W = 3, 61, 304
+    g, h, s = make_inputs(B, H, W, seed=4242, sparse=True, neg=True, depth_scale=80.0)
+    g[1, :, 20:23, 100:108] = 0.0
+    for n in range(1, 51):
+        for norm in (("8sum",) if n % 5 else ("8sum", "8sum_abs")):
+            a = _run(g, h, s if n % 2 else None, n, norm, "fused")
+            b = _run(g, h, s if n % 2 else None, n, norm, "fused_cxx")
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (n, norm)
+            assert rel_err(a, b) <= 1e-5, (n, norm, rel_err(a, b))
+            if n in (1, 7, 12, 23, 25, 47):
+                assert_close_tight(a, cspn2d_oracle(g, h, s if n % 2 else None, n, norm), "n_iter %d" % n)
 
 
 @pytest.mark.parametrize("B,H,W,norm,sp", [(2, 40, 256, "8sum", True), (1, 70, 516, "8sum_abs", False), (3, 33, 304, "none", True),

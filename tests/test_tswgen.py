@@ -123,8 +123,8 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
 
 
 def test_generated_include_is_current_and_hazard_free(tmp_path, monkeypatch):
-    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 23 variants (16 forward: 4 norms incl. round 5's
-    prenorm x mask x continuation pass, 6 history, the adjoint sweep) -- and every one of them passes the static hazard rules (K.build
+    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 31 variants (16 forward: 4 norms incl. round 5's
+    prenorm x mask x continuation pass, 8 short first passes (n < 24 iterations), 6 history, the adjoint sweep) -- and every one of them passes the static hazard rules (K.build
     raises on a hazard)"""
     from tools.tswgen import emit
     out = tmp_path / "gen.inc"
@@ -132,7 +132,7 @@ def test_generated_include_is_current_and_hazard_free(tmp_path, monkeypatch):
     emit.main()
     new = out.read_text()
     old = open(os.path.join(ROOT, "cspn_amd", "csrc", "cspn2d_tsw_gen.inc")).read()
-    assert new.count("#define TSW_ASM_") == 23
+    assert new.count("#define TSW_ASM_") == 31
     assert new == old, "cspn_amd/csrc/cspn2d_tsw_gen.inc is stale: python -m tools.tswgen.emit"
 
 
@@ -181,6 +181,21 @@ def test_scheduler_respects_hazards_and_emulator_flags_misuse():
         else:
             with pytest.raises(EmuError, match="race"):
                 e.run()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(B=3, H=30, W=304, n_wg=4, norm=0, sparse=True, early_n=7),                       # slots 2 / 3 deliver (saved copy / LDS boundary row)
+    dict(B=2, H=37, W=260, n_wg=3, norm=1, sparse=False, early_n=22, zero_patch=True),    # the stored level wraps into the next ring cycle; NaN patch
+    dict(B=2, H=30, W=304, n_wg=2, norm=3, sparse=False, early_n=13, linear=3),           # linear plan: pieces that change band (mask re-derived in the stub)
+    dict(B=1, H=5, W=256, n_wg=1, norm=2, sparse=True, early_n=1),                        # one iteration, fewer rows than a ring cycle
+])
+def test_emulated_short_pass_vs_oracle(kw):
+    """generator cfg `early` (round 5): a first pass of n < 24 iterations -- the ring runs its 24 levels, a row is stored at the end of the
+    step in which it completed level n (out-of-line stub behind one scalar test per step), nothing at its retirement"""
+    os.chdir(ROOT)
+    err, nanmis, out, ref = run_case(verbose=False, **kw)
+    assert nanmis == 0 and err <= 1e-5, kw
+    assert not kw.get("zero_patch") or np.isnan(ref).any()
 
 
 @pytest.mark.parametrize("sched_seed", [None, 7])

@@ -21,6 +21,7 @@ P
 python tools/rocpd_summary.py ${O}_prof/*/*.db ${O}_kernel_stats_driver_cmd.md | head -14 | cut -c1-200; rm -rf ${O}_prof
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/${O}_prof -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs) > ${O}_prof.log 2>&1
 python tools/rocpd_summary.py ${O}_prof/*/*.db ${O}_kernel_stats_headline_only.md | head -4 | cut -c1-200; rm -rf ${O}_prof
+timeout 300 python bench.py --workload kitti_n12 --steps 50 --warmup 10 --no-cpu-baseline > ${O}_bench_n12.json 2>> ${O}_bench.err; python -c "import json;d=json.load(open('${O}_bench_n12.json'));print('n12',d['ms_per_step'],d['roofline']['device_ms_per_launch'],d['roofline']['frac'],d['parity_checked']['ok'])"
 for seed in 11 12; do FUZZ_CASES=40 FUZZ_SEED=$seed timeout 900 python tools/fuzz_parity.py 2>&1 | tail -1; done | tee ${O}_fuzz.txt
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 2> ${O}_bench_2rank.err | grep "^{" > ${O}_bench_2rank.json
 python -c "import json;d=json.load(open('${O}_bench_2rank.json'));print('2rank',d['n_gpus'],d['ms_per_step'],d['roofline']['frac'],d.get('strong',{}).get('roofline_frac_per_gpu'),d['parity_checked']['ok'],d.get('notes'))"

@@ -109,6 +109,10 @@ S_WF = S(50, 2)     # history mode: the 8 folded coefficient planes w'_k ([8][B*
 S_PBOFF = S(47)     # history mode: byte offset (1-channel tensor) of the pending task's row
 S_CMASK = S(52, 2)  # history mode: cooking lanes (2 pixels each) whose pixels lie in the band's owned columns
 T = [S(68 + i) for i in range(12)]  # scalar temporaries s68..s79
+# cfg early (forward variants; s92:95 are the history variants' inputs): a pass of n < 24 iterations -- a row's output is the level n it reaches n
+# steps after its injection; it then stays in its slot, harmlessly, until the slot's next event
+SAVE2 = [V(70), V(71), V(74), V(75)]   # cfg early: copy of slot 2's completed quad (its accumulator is re-initialised by slot 1's pushes in the same step); PEND_HIN / V_DN are unused there
+S_NIT, S_EMASK = S(94), S(95)   # inputs: n (1..23); bit c set <=> some slot of a wave completes level n in the step with ring counter c: c = n .. n + 3 (mod 24)
 # cfg elastic (never together with hist / hin / pf / trace, whose registers these are)
 S_MBR, S_TWU, S_TWD, S_RTW = [S(84), S(85)], [S(86), S(87)], [S(88), S(89)], [S(90), S(91)]   # LDS addresses, per counter parity
 S_RTR, S_EXP, S_EXR, S_SPIN, S_MB0, S_EXW = S(96), S(97), S(98), S(99), S(92), S(93)
@@ -141,6 +145,13 @@ class Gen(object):
         self.s8 = cfg.get("s8", False)
         if self.s8:
             assert not self.adj and not self.hist
+        # early (round 5): the pass delivers level n < 24 (n at run time, S_NIT): the ring still runs its 24 levels (rows live 24 steps, the band halo and
+        # the warm-up rows stay 24 deep), but a row is STORED at the end of the step in which it completed level n, by an out-of-line stub that one
+        # scalar test per step (S_EMASK bit c) guards; nothing is stored at retirement.  n_iter = 24 k + r runs r iterations here first, then k full passes.
+        self.early = cfg.get("early", False)
+        if self.early:
+            assert not (self.hist or self.adj or self.s8 or self.hin or cfg.get("elastic") or cfg.get("stagger") or cfg.get("pf"))
+        self.xstubs, self.xstub_of = [], {}
         self.given = self.norm in (2, 3)   # coefficients are used as given, centre-sited (3: with the centre term, 2: without)
         if self.norm == 3:
             assert not self.adj and not self.hist and not self.s8
@@ -274,7 +285,10 @@ class Gen(object):
         for k in range(4):
             self.e("v_readfirstlane_b32", S_CD[k], [V_DC[k]])
 
-    def retire(self, j, vq):
+    def retire(self, j, vq, at_event=True):
+        """at_event = False (cfg early): j is a scalar register holding the slot number, OUTQ is loaded already"""
+        if self.early and at_event:
+            return   # (cfg early: the row's output left at level n, see the end of step() / emit_early_stub)
         eo = S_EO
         lab = self.p.newlabel("noret")
         self.e("s_bitcmp1_b32", (), [S_ACT, j])
@@ -288,10 +302,11 @@ class Gen(object):
             self.e("s_cbranch_scc1", (), [stub])
             self.p.label(back)
             self.mstubs.append((stub, back))
-        self.mov(OUTQ[0], vq[0])   # registers hold (c0,c3,c1,c2)
-        self.mov(OUTQ[1], vq[2])
-        self.mov(OUTQ[2], vq[3])
-        self.mov(OUTQ[3], vq[1])
+        if vq is not None:
+            self.mov(OUTQ[0], vq[0])   # registers hold (c0,c3,c1,c2)
+            self.mov(OUTQ[1], vq[2])
+            self.mov(OUTQ[2], vq[3])
+            self.mov(OUTQ[3], vq[1])
         self.e("s_add_u32", T[8], [S_OUT[0], eo[0]])
         self.e("s_addc_u32", T[9], [S_OUT[1], 0])
         self.e("s_mov_b64", EXEC, [S_OMASK])   # the owned columns of the row's band (mband: kept current by the check above)
@@ -522,6 +537,9 @@ class Gen(object):
                 self.act_check(j, vq)
             if self.hist and ev != j and ((c - j) % LV) % self.hist_every == 0:   # slot j has just completed level (c - j) mod 24
                 self.hist_store(j, vq)
+            if self.early and j == 2 and ev != 2:   # (slots 0, 1 keep their values to the end of the step; slot 3's is in the LDS boundary row)
+                for i in range(4):
+                    self.mov(SAVE2[i], vq[i])
             if j == 3 and "nolds" not in self.ab:
                 self.e("ds_write_b128", (), [V_WR[p], vq], offset=1024, at=0.0)
                 if self.elastic:   # the wave below reads this row as its "top": its mailbox, entry 0
@@ -550,6 +568,18 @@ class Gen(object):
         self.probe(3)
         if prio:
             self.e("raw", (), ["s_setprio 0"])
+        if self.early:   # did a slot of this wave complete level n in this step?  (4 of the 24 counters; the stub stores the row)
+            # The slow body shares the fast body's stub AND its return point: from here on the two bodies do the same (wait, barrier, count,
+            # go to the next counter's fast label, which dispatches on vcc again)
+            assert not self.cfg.get("trace", False)
+            if not slow:
+                self.xstub_of[c] = (self.p.newlabel("early"), self.p.newlabel("eback"))
+                self.xstubs.append(self.xstub_of[c] + (c, [N1[0], N1[1], SAVE2, None], V_WR[p]))
+            stub, back = self.xstub_of[c]
+            self.e("s_bitcmp1_b32", (), [S_EMASK, c])
+            self.e("s_cbranch_scc1", (), [stub])
+            if not slow:
+                self.p.label(back)
         if not self.elastic:
             self.p.waitcnt(lgkm=0)
         self.probe(4)
@@ -1165,6 +1195,43 @@ class Gen(object):
             e("s_cmp_eq_u32", (), [S_WV, w])
             e("s_cbranch_scc1", (), [(".LH" if self.cfg.get("stagger", False) and w >= NW // 2 else ".LS") + "%d_%%=" % c0])
 
+    def emit_early_stub(self, stub, back, c, vqs, v_wr):
+        """cfg early, end of the step with ring counter c: slot j has just completed level (c - j) mod 24; the one whose level is n (S_NIT) is stored
+        exactly as a retirement would store it -- its descriptor is fetched again from the LDS table (stream row S_QB + j, or that - 32 once
+        slot 3's injection of this cycle has moved S_QB on), so the linear plan's band changes (mband) work unchanged"""
+        self.p.label(stub)
+        cand = [j for j in range(4) if (c - j) % LV != 0]   # (level 0 = the slot had its event in this step: never an early output)
+        sel = {j: self.p.newlabel("esel") for j in cand}
+        common = self.p.newlabel("ecommon")
+        for j in cand:
+            self.e("s_cmp_eq_u32", (), [S_NIT, (c - j) % LV])
+            self.e("s_cbranch_scc1", (), [sel[j]])
+        self.e("s_branch", (), [back])
+        for j in cand:
+            self.p.label(sel[j])
+            vq = vqs[j]
+            if j == 3:   # published as the wave's last row in this step (LDS operations of a wave complete in order)
+                self.e("ds_read_b128", TQ, [v_wr], offset=1024)
+                self.p.waitcnt(lgkm=0)
+                vq = TQ
+            self.mov(OUTQ[0], vq[0])   # registers hold (c0,c3,c1,c2)
+            self.mov(OUTQ[1], vq[2])
+            self.mov(OUTQ[2], vq[3])
+            self.mov(OUTQ[3], vq[1])
+            self.e("s_mov_b32", T[0], [j])
+            self.e("s_add_i32", T[1], [S_QB, j if j < c < 3 else j - 32])
+            self.e("s_branch", (), [common])
+        self.p.label(common)
+        self.e("s_lshl_b32", T[1], [T[1], 4])
+        self.e("s_add_i32", T[1], [T[1], S_TABB])
+        self.mov(V_DO[0], T[1])
+        self.e("ds_read_b64", V_DO, [V_DO[0]], offset=8)
+        self.p.waitcnt(lgkm=0)
+        self.e("v_readfirstlane_b32", S_EO[0], [V_DO[0]])
+        self.e("v_readfirstlane_b32", S_EO[1], [V_DO[1]])
+        self.retire(T[0], None, at_event=False)
+        self.e("s_branch", (), [back])
+
     def build(self):
         self.prologue()
         stag = self.cfg.get("stagger", False)
@@ -1192,6 +1259,8 @@ class Gen(object):
             self.e("s_cbranch_scc1", (), [back])
             self.zero_quad(vq)
             self.e("s_branch", (), [back])
+        for st in self.xstubs:
+            self.emit_early_stub(*st)
         for stub, back in self.mstubs:
             # the band changed: S_OMASK <- lanes [lo / 4, hi / 4) of the new band (T[10] = lo | hi << 12, from retire())
             self.p.label(stub)

@@ -11,8 +11,9 @@ from .plan import build_plan
 
 
 def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=False, verbose=True, sched=True, hist=False, hist_every=1,
-             s8=False, elastic=False, sched_seed=None, linear=None, cfg_extra=None):
-    """linear = number of CUs: the forward passes' linear plan (tools/tswgen/plan.py LinearPlan: one contiguous piece of the
+             s8=False, elastic=False, sched_seed=None, linear=None, cfg_extra=None, early_n=None):
+    """early_n = n (1..23): the `early` variant -- a pass that delivers level n (checked against the oracle run for n iterations).
+    linear = number of CUs: the forward passes' linear plan (tools/tswgen/plan.py LinearPlan: one contiguous piece of the
     band-row order per CU; a piece may continue in the next band) instead of band groups"""
     sys.path.insert(0, ".")
     from oracle import oracle as O
@@ -34,7 +35,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         hinv = (rng.random((B, 1, H, W)) * 10).astype(np.float32)
     K.configure(elastic)
     prog = K.build(dict(norm=norm, sparse=sparse, hin=hin, hist=hist, hist_every=hist_every, s8=s8, elastic=elastic, **({"act_and": False} if s8 else {}),
-                        **(cfg_extra or {})), sched=sched)
+                        **({"early": True} if early_n else {}), **(cfg_extra or {})), sched=sched)
     g_dev = sited8(g, norm) if s8 else g   # what the kernel reads as its guidance tensor
     if norm == 3:   # prenorm: the kernel reads what reference affinity_normalization returns for the RAW guidance g ('8sum'); the oracle
         g_dev = normalized_planes(g, 0)    # below still sees the raw tensors
@@ -92,6 +93,10 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
             if hist:
                 set64(K.S_HIST, off["hist"])
                 set64(K.S_HSTRIDE, blur.nbytes)
+            if early_n:
+                assert 1 <= early_n <= 23 and not hin
+                w.s[K.S_NIT.i] = early_n
+                w.s[K.S_EMASK.i] = sum(1 << ((early_n + j) % 24) for j in range(4))
             w.s[K.S_W4.i] = 4 * W
             w.s[K.S_HW4.i] = 4 * H * W
             w.s[K.S_LAST.i] = int(hdr[wg, 1])
@@ -106,7 +111,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         # oracle for a continuation pass: propagate hinv with blur as H0 ... the oracle has no such entry; emulate with numpy
         ref = ref_hin(g, blur, sp, hinv, n_iter, norm)
     else:
-        ref = O.cspn2d_oracle(g, blur, sp, n_iter, ["8sum", "8sum_abs", "none", "8sum"][norm])
+        ref = O.cspn2d_oracle(g, blur, sp, early_n or n_iter, ["8sum", "8sum_abs", "none", "8sum"][norm])
     if hist:
         assert not hin
         npl = 24 // hist_every - 1   # level planes: levels hist_every, 2 hist_every ..
