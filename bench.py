@@ -43,7 +43,7 @@ WORKLOADS = {
     "plumbing": (228, 304, 12, False, 10.0, "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)"),
     # off the fast path (round-4 review, weak 8): measured for the record, not part of the driver's line
     "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (BASELINE config 1's count; the reference's own defaults are 24, cspn_paddle/demo.py:92): one short pass of the assembly loop (round 5: a row is stored when it completes level 12)"),
-    "kitti_w1218": (304, 1218, 24, False, 80.0, "304x1218 (W % 4 != 0), 24 iterations: fold + one launch per iteration"),
+    "kitti_w1218": (304, 1218, 24, False, 80.0, "304x1218 (W % 4 != 0), 24 iterations: rows padded to 1220 columns in the workspace, fused path on those (round 5; before: fold + one launch per iteration)"),
 }
 
 
@@ -59,7 +59,7 @@ def parse():
                          "batch 64 sharded over the GPUs of the node, the scatter of reference cspn_pytorch/eval.py:115-118) cut into "
                          "contiguous per-rank chunks, rank r owns images [r G / N, (r + 1) G / N)")
     ap.add_argument("--global-batch", type=int, default=64)
-    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx", "fused_padded"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -386,6 +386,10 @@ def roofline2d(m):
         "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
                   "stream of its piece of the linear plan in LDS, nothing else runs inside the timed region)"
                   if algo_name == "fused" and W >= 256 and W % 4 == 0 and n_iter == 24
+                  else "cspn2d_tsw_kernel (gfx950 assembly main loop; a short first pass of %d iterations%s)" % (n_iter % 24, " + %d passes of 24" % (n_iter // 24) if n_iter >= 24 else "")
+                  if algo_name == "fused" and W >= 256 and W % 4 == 0
+                  else "normalize2d_pitch_kernel / pad_rows_kernel -> the fused path on rows padded to a multiple of 4 columns -> unpad_rows_kernel (whole forward)"
+                  if algo_name == "fused_padded"
                   else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
                   else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
         "achieved": round(m["achieved"], 1),
@@ -577,7 +581,7 @@ def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, 
         first = rank * B
     g, h, s = synth(B, H, W, scale, sparse, dev, first=first)
     algo_id = _lib.ALGOS[a.algo] or lib.cspn2d_auto_algo(B, H, W, n_iter)
-    algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx"}[algo_id]
+    algo_name = {1: "stepwise", 2: "fused", 3: "fused_cxx", 4: "fused_padded"}[algo_id]
     norm = _lib.NORM_TYPES[a.norm_type]
     ws_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)

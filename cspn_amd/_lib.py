@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("CSPN_AMD_LIB") or os.path.join(_HERE, "libcspn_amd.so
 CSRC = os.path.join(_HERE, "csrc")
 
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2, "prenorm": 3}
-ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3}
+ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3, "fused_padded": 4}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
 ABI_VERSION = 4
 

@@ -65,13 +65,15 @@ int cspn_abi_version(void) { return CSPN_ABI_VERSION; }
 const char* cspn_last_error(void) { return g_err; }
 
 int cspn2d_auto_algo(int B, int H, int W, int n_iter) {
-    return fused2d_supported(B, H, W, n_iter) ? CSPN_ALGO_FUSED : CSPN_ALGO_STEPWISE;
+    if (fused2d_supported(B, H, W, n_iter)) return CSPN_ALGO_FUSED;
+    return padded2d_supported(B, H, W, n_iter) ? CSPN_ALGO_FUSED_PADDED : CSPN_ALGO_STEPWISE;
 }
 
 size_t cspn2d_workspace_bytes(int B, int H, int W, int n_iter) {
     if (B <= 0 || H <= 0 || W <= 0 || n_iter <= 0) return 0;
     size_t a = stepwise2d_workspace(B, H, W, n_iter);
     size_t b = fused2d_supported(B, H, W, n_iter) ? fused2d_workspace(B, H, W, n_iter) : 0;
+    if (padded2d_supported(B, H, W, n_iter)) b = padded2d_workspace(B, H, W, n_iter);
     return a > b ? a : b;  // large enough for either algo so callers can A/B
 }
 
@@ -82,7 +84,15 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
     if (B == 0) return 0;
     if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (algo == CSPN_ALGO_AUTO) algo = cspn2d_auto_algo(B, H, W, n_iter);
+    if (algo == CSPN_ALGO_AUTO) {
+        algo = cspn2d_auto_algo(B, H, W, n_iter);
+        if (algo == CSPN_ALGO_FUSED && ((uintptr_t)out & 15u) != 0) algo = CSPN_ALGO_STEPWISE;   // (the fused kernels store aligned float4)
+    }
+    if (algo == CSPN_ALGO_FUSED_PADDED) {
+        if (!padded2d_supported(B, H, W, n_iter)) { set_error("FUSED_PADDED is for W %% 4 != 0 (B=%d H=%d W=%d n_iter=%d)", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
+        if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, padded2d_workspace(B, H, W, n_iter), CSPN_NORM_PRENORM)) return e;
+        return padded2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
+    }
     if (algo != CSPN_ALGO_STEPWISE && algo != CSPN_ALGO_FUSED && algo != CSPN_ALGO_FUSED_CXX) { set_error("unknown algo %d", algo); return CSPN_E_BADARG; }
     const bool fused = algo == CSPN_ALGO_FUSED || algo == CSPN_ALGO_FUSED_CXX;
     if (fused && !fused2d_supported(B, H, W, n_iter)) {

@@ -33,6 +33,11 @@ int stepwise2d_forward(const float* g, const float* blur, const float* sparse, f
                        int n_iter, int norm, void* ws, hipStream_t st);
 // reference affinity_normalization (cspn.py:85-144) as a stand-alone kernel: g [B,8,H,W] -> gate_wb [B,8,H,W] (norm 8SUM / 8SUM_ABS)
 int normalize2d(const float* g, float* wb, int B, int H, int W, int norm, hipStream_t st);
+// W % 4 != 0: the fused path on rows padded to a multiple of 4 columns (cspn2d_stepwise.hip)
+bool padded2d_supported(int B, int H, int W, int n_iter);
+size_t padded2d_workspace(int B, int H, int W, int n_iter);
+int padded2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W, int n_iter, int norm, void* ws,
+                     hipStream_t st);
 size_t stepwise3d_workspace(int B, int D, int H, int W, int n_iter);
 int stepwise3d_forward(const float* g, const float* feat, const float* sparse, float* out, int B, int D, int H,
                        int W, int n_iter, int norm, void* ws, hipStream_t st, int algo = 0);

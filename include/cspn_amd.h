@@ -58,7 +58,10 @@ enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2,
  * least 256 columns wide through the assembly main loop for EVERY n_iter (round 5): n_iter = 24 k + r is one short first pass
  * of r iterations (a row is stored when it completes level r) followed by k passes of 24 -- one launch per pass, 40 / 44 B
  * per pixel and pass; narrower images and FUSED_CXX (A/B tests) take the compiler-generated version of the same kernel. */
-enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2, CSPN_ALGO_FUSED_CXX = 3 };
+enum { CSPN_ALGO_AUTO = 0, CSPN_ALGO_STEPWISE = 1, CSPN_ALGO_FUSED = 2, CSPN_ALGO_FUSED_CXX = 3,
+       CSPN_ALGO_FUSED_PADDED = 4 /* W % 4 != 0 (what AUTO picks there, round 5): the inputs are laid out once in the workspace with rows padded to a
+                                    * multiple of 4 columns (zeros; 8SUM / 8SUM_ABS are normalised on the way, for the real width), the fused path
+                                    * runs on those and the output is copied back: three more passes over the data instead of one launch per iteration */ };
 
 enum {
     CSPN_E_BADARG = -1,   /* null pointer, non-positive size, unknown enum      */

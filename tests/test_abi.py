@@ -35,6 +35,11 @@ def test_abi_version_and_workspace_sizes():
     assert lib.cspn2d_workspace_bytes(2, 228, 304, 24) >= 2 * 228 * 304 * 4
     assert lib.cspn3d_workspace_bytes(1, 4, 8, 8, 3) >= 27 * 4 * 8 * 8 * 4
     assert lib.cspn2d_auto_algo(64, 304, 1216, 24) in (_lib.ALGOS["stepwise"], _lib.ALGOS["fused"])
+    # round 5: W % 4 != 0 no longer means one launch per iteration -- AUTO pads the rows to a multiple of 4 columns in the workspace
+    assert lib.cspn2d_auto_algo(64, 304, 1218, 24) == _lib.ALGOS["fused_padded"] == 4
+    assert lib.cspn2d_auto_algo(1, 7, 5, 3) == _lib.ALGOS["fused_padded"]
+    assert lib.cspn2d_workspace_bytes(2, 30, 302, 24) >= 11 * 2 * 30 * 304 * 4
+    assert lib.cspn2d_workspace_bytes(2, 30, 302, 30) >= 12 * 2 * 30 * 304 * 4   # + the ping buffer of the second pass
 
 
 def test_argument_errors_are_reported_without_gpu():

@@ -18,6 +18,8 @@ DEV = "cuda:0"
 def _algos(B, H, W, N):
     lib = cspn_amd.load()
     algos = ["stepwise"]
+    if N > 0 and lib.cspn2d_auto_algo(B, H, W, N) == _lib.ALGOS["fused_padded"]:
+        algos += ["fused_padded", "auto"]
     if N > 0 and lib.cspn2d_auto_algo(B, H, W, N) == _lib.ALGOS["fused"]:
         algos.append("fused")
         algos.append("fused_cxx")
@@ -508,6 +510,38 @@ def test_asm_loop_parity_vs_oracle(B, H, W, N, norm, sp):
     outs = {a: _run(g, h, s, N, norm, a) for a in ("fused", "fused_cxx", "fused_groups", "fused_noxcd")}
     for a, o in outs.items():
         assert_close_tight(o, ref, a)
+
+
+@pytest.mark.parametrize("B,H,W,N,norm,sp", [(2, 41, 302, 24, "8sum", True),       # W % 4 = 2: assembly loop on 304-column rows
+                                             (1, 30, 1217, 24, "8sum_abs", False),  # W % 4 = 1, several bands
+                                             (3, 37, 259, 30, "8sum", True),        # W % 4 = 3: 256 real columns + 3; short pass + full pass (ping buffer)
+                                             (2, 19, 50, 7, "8sum", True),          # narrow: the compiler-generated kernel on 52 columns
+                                             (2, 33, 301, 24, "none", True),        # gates used as given: copied, not normalised
+                                             (1, 25, 270, 12, "prenorm", False)])
+def test_width_not_a_multiple_of_four_takes_the_padded_fused_path(B, H, W, N, norm, sp):
+    """round 5: W % 4 != 0 ran fold + one launch per iteration (4.85 ms at 304 x 1218 x 64 against 0.28 for 304 x 1216).  AUTO now lays the
+    inputs out with rows padded to a multiple of 4 columns (zeros; 8sum / 8sum_abs normalised on the way, for the REAL width) and runs the
+    fused path on those: the pad columns must behave exactly like the reference's zero padding outside the image -- NaN patch (0/0),
+    negative-sparse points and the right image edge included"""
+    assert cspn_amd.load().cspn2d_auto_algo(B, H, W, N) == _lib.ALGOS["fused_padded"]
+    g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp, depth_scale=80.0)
+    g[0, :, 9:12, W - 9:W - 2] = 0.0      # zero guidance next to the right edge: 0/0 -> NaN must spread exactly as in the reference
+    gr = g
+    if norm == "none":
+        g = g.abs() / (g.abs().sum(1, keepdim=True) + 0.25)
+        ref = cspn2d_oracle(g, h, s, N, "none")
+    elif norm == "prenorm":
+        from oracle.oracle import cspn2d_gate_wb_oracle
+        ref = cspn2d_oracle(gr, h, s, N, "8sum")
+        g = torch.from_numpy(cspn2d_gate_wb_oracle(gr.numpy(), "8sum"))
+    else:
+        ref = cspn2d_oracle(g, h, s, N, norm)
+    for algo in ("auto", "fused_padded", "stepwise"):
+        o = _run(g, h, s, N, norm, algo)
+        assert_close_tight(o, ref, algo)
+    # explicit FUSED stays an error for such a width (the caller asked for a kernel that cannot take it)
+    with pytest.raises(Exception):
+        _run(g, h, s, N, norm, "fused")
 
 
 def test_asm_loop_every_iteration_count_matches_the_compiled_kernel():
