@@ -417,7 +417,7 @@ __device__ __attribute__((noinline)) void bwd_epilogue4_2pass(const float* __res
 #endif
 constexpr int CK = 4, CK_GR = 16, CK_TG = CK_GR - 2, NCKP = 24 / CK - 1;   // NCKP: level planes a sweep keeps
 
-__device__ __forceinline__ float4 reg_to_img(float4 q) { return make_float4(q.x, q.z, q.w, q.y); }   // (c0,c3,c1,c2) -> (c0..c3)
+[[maybe_unused]] __device__ __forceinline__ float4 reg_to_img(float4 q) { return make_float4(q.x, q.z, q.w, q.y); }   // (c0,c3,c1,c2) -> (c0..c3)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt 0), i.e. for the next
