@@ -6,6 +6,6 @@ cd "$(dirname "$0")/../../cspn_amd/csrc"
 mkdir -p ../abl build
 make -s -j8 2>/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DP3_EXPERIMENT_BUILD $2 -x hip -c cspn3d_persistent.hip -o build/p3var_$1.o
-OBJS="build/cspn_abi.cpp.o build/cspn2d_stepwise.hip.o build/cspn3d_stepwise.hip.o build/cspn3d_backward.hip.o build/cspn2d_fused.hip.o build/cspn2d_backward.hip.o build/cspn_aux.hip.o build/cspn2d_tsw.p0.o build/cspn2d_tsw.p3.o build/cspn2d_tsw.p4.o build/cspn2d_tsw.p6.o build/cspn2d_tsw.p1.o build/cspn2d_tsw.p5.o"
+OBJS="build/cspn_abi.cpp.o build/cspn2d_stepwise.hip.o build/cspn3d_stepwise.hip.o build/cspn3d_backward.hip.o build/cspn2d_fused.hip.o build/cspn2d_backward.hip.o build/cspn_aux.hip.o build/cspn2d_tsw.p0.o build/cspn2d_tsw.p3.o build/cspn2d_tsw.p4.o build/cspn2d_tsw.p6.o build/cspn2d_tsw.p1.o build/cspn2d_tsw.p5.o build/cspn2d_tsw.p7.o build/cspn2d_tsw.p8.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/libcspn_$1.so $OBJS build/p3var_$1.o
 echo built cspn_amd/abl/libcspn_$1.so
