@@ -42,7 +42,8 @@ extern "C" {
 
 #define CSPN_ABI_VERSION 4   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32;
                               * 4: CSPN_NORM_PRENORM, cspn2d_normalize_f32, cspn2d_forward_prenorm_f32, cspn3d_backward_multi_f32; the
-                              *    sited8 experiment's three entry points left the ABI (hook library, experiment builds) */
+                              *    sited8 experiment's three entry points left the ABI (hook library, experiment builds); CSPN_ALGO_FUSED_PADDED
+                              *    (what AUTO returns for W % 4 != 0; cspn2d_workspace_bytes grows accordingly for such widths) */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
