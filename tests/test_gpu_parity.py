@@ -710,9 +710,12 @@ def test_asm_paths_are_deterministic():
     s = (torch.rand(B, 1, H, W, generator=gen, device=DEV) < 0.01).float() * (h + 0.1)
     go = torch.randn(B, 1, H, W, generator=gen, device=DEV)
     ref = cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused")
+    short = {n: cspn_amd.cspn2d_forward(g, h, s, n, "8sum", "fused") for n in (5, 14, 23, 31)}   # round 5: the short first pass (+ a full pass)
     gg0, gh0 = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
     for i in range(12):
         assert torch.equal(cspn_amd.cspn2d_forward(g, h, s, 24, "8sum", "fused"), ref)
+        for n, r in short.items():
+            assert torch.equal(cspn_amd.cspn2d_forward(g, h, s, n, "8sum", "fused"), r), n
         if i % 4 == 0:
             gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, 24, "8sum")
             assert torch.equal(gg, gg0) and torch.equal(gh, gh0)
