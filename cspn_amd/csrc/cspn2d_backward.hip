@@ -434,8 +434,9 @@ template <int CK_ROWS>
 __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_final_ck_kernel(
     const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
     const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
-    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
-    constexpr int N = 24, NSEG = N / CK, CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm, int nseg) {
+    constexpr int CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    const int NSEG = nseg;   // n_iter / 4 segments of four levels (round 5: n_iter = 4, 8 .. 24; 6 for the reference's 24)
     __shared__ __attribute__((aligned(16))) float4 sH[2][CK_NT];       // H_{s+l} of the region, two planes alternating (image order inside a quad)
     __shared__ __attribute__((aligned(16))) float4 sA[CK][CK_NT];      // A_{s+1} .. A_{s+4}: every thread's own group only
     __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
@@ -514,9 +515,9 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     float4 nh = seg_h(0), na = seg_a(0);   // the checkpoints are requested one segment ahead
     int par = 0;
 #ifdef BWD_EXP_NOLOOP
-    constexpr int NSEG_RUN = 0;
+    const int NSEG_RUN = 0;
 #else
-    constexpr int NSEG_RUN = NSEG;
+    const int NSEG_RUN = NSEG;
 #endif
     // the whole segment loop, twice: blocks whose region lies inside the image (two thirds of them at KITTI size) need no
     // "outside the image -> 0" selects
@@ -633,8 +634,9 @@ template <int CK_ROWS>
 __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu(CK_ROWS / 16, CK_ROWS / 16))) void bwd_final_mx_kernel(
     const float* __restrict__ g, const float* __restrict__ blur, const float* __restrict__ sparse, const float* __restrict__ hh,
     const float* __restrict__ ah, const float* __restrict__ wf, const float* __restrict__ a0p, const float* __restrict__ gout,
-    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm) {
-    constexpr int N = 24, NSEG = N / CK, CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    float* __restrict__ gg, float* __restrict__ gb, int B, int H, int W, int norm, int nseg) {
+    constexpr int CK_NT = CK_ROWS * CK_GR, CK_TR = CK_ROWS - 2 * CK;
+    const int NSEG = nseg;   // n_iter / 4 segments of four levels (round 5: n_iter = 4, 8 .. 24; 6 for the reference's 24)
     __shared__ __attribute__((aligned(16))) float4 sH[2][CK_NT];       // H_{s+l} of the region, two planes alternating (REGISTER order inside a quad)
     __shared__ __attribute__((aligned(16))) float4 sA[CK][CK_NT];      // A_{s+1} .. A_{s+4}: every thread's own group only
     __shared__ __attribute__((aligned(16))) float4 sT[2][2][CK_NT];    // [parity][to the row below | above]
@@ -834,8 +836,11 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
 
 constexpr size_t FRONT_PAD = 65536;  // bytes kept addressable in front of the folded planes (the adjoint sweep reads plane 0
                                      // one row up and one pixel left of its first row)
+// n_iter = 4, 8 .. 24 (round 5; rounds 3-4: 24 only).  The sweeps always run the ring's 24 levels; for n_iter < 24 the levels beyond n_iter are
+// computed and ignored: the forward's result H_n is its checkpoint plane n/4 - 1, the adjoint sweep started from A_n = dL/dout leaves A_{n-4-4i} in its
+// plane i and A_0 in plane n/4 - 1 (both in register order: reg_to_img_plane below), and the final pass runs n/4 segments.
 static bool asm_path(int B, int H, int W, int n_iter) {
-    return n_iter == 24 && tsw2d_supported(B, H, W) && 4ull * W + 16 <= FRONT_PAD &&
+    return n_iter >= 4 && n_iter <= 24 && (n_iter % 4) == 0 && tsw2d_supported(B, H, W) && 4ull * W + 16 <= FRONT_PAD &&
            (unsigned long long)B * H * W * 32ull < (1ull << 32);  // 8 coefficient planes of per-lane byte offsets
 }
 
@@ -846,9 +851,18 @@ size_t backward2d_workspace(int B, int H, int W, int n_iter) {
     return (size_t)(9 + 8 + (n_iter > 0 ? n_iter - 1 : 0) + n_iter) * total * sizeof(float);
 }
 
+// a level plane in the sweeps' register order (c0,c3,c1,c2 per aligned 4-column group) -> image order
+__global__ __launch_bounds__(256) void reg_to_img_plane_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) { const float4 q = src[i]; dst[i] = make_float4(q.x, q.z, q.w, q.y); }
+}
+static void reg_to_img_plane(const float* src, float* dst, size_t total, hipStream_t st) {
+    hipLaunchKernelGGL(reg_to_img_plane_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, (const float4*)src, (float4*)dst, total / 4);
+}
+
 // final pass of the assembly-sweep backward: from the checkpoints of both sweeps
 static void launch_final_ck(const float* g, const float* blur, const float* sparse, const float* hh, const float* ah, const float* wf,
-                            const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, hipStream_t st) {
+                            const float* a0, const float* gout, float* gg, float* gb, int B, int H, int W, int norm, int nseg, hipStream_t st) {
 #ifdef BWD_FINAL_ROWS   // (A/B build: 64 = 1 024 threads, four waves per SIMD at 128 registers, all 160 KB of LDS)
     constexpr int ROWS = BWD_FINAL_ROWS, TROWS = ROWS - 2 * CK;
 #else
@@ -857,10 +871,10 @@ static void launch_final_ck(const float* g, const float* blur, const float* spar
     const int ntile = ((W / 4 + CK_TG - 1) / CK_TG) * ((H + TROWS - 1) / TROWS) * B, per = (ntile + 7) / 8;
 #ifdef BWD_FINAL_CK   // (A/B build: the round-3 kernel, image-order pixel pairs)
     hipLaunchKernelGGL(bwd_final_ck_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
-                       gg, gb, B, H, W, norm);
+                       gg, gb, B, H, W, norm, nseg);
 #else
     hipLaunchKernelGGL(bwd_final_mx_kernel<ROWS>, dim3((unsigned)(per * 8)), dim3(ROWS * CK_GR), 0, st, g, blur, sparse, hh, ah, wf, a0, gout,
-                       gg, gb, B, H, W, norm);
+                       gg, gb, B, H, W, norm, nseg);
 #endif
 }
 
@@ -878,9 +892,11 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
         float* ah = wf + 8 * total;
         float* a0 = ah + NCKP * total;
         float* scratch = a0 + total;
+        const int nseg = n_iter / CK;
         if (int e = tsw2d_pass(g, blur, blur, sparse, scratch, B, H, W, norm, st, hh)) return e;
         if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-        launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, st);
+        if (nseg <= NCKP) reg_to_img_plane(ah + (size_t)(nseg - 1) * total, a0, total, st);   // A_0 of a sweep shorter than the ring
+        launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, nseg, st);
         return check_launch("bwd_final_ck_kernel");
     }
     float* wt = wf + 9 * total;                       // transposed coefficients of the adjoint stencil
@@ -909,10 +925,16 @@ size_t history2d_bytes(int B, int H, int W, int n_iter) {
 }
 
 int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
-                      int norm, void* ws, hipStream_t st) {
+                      int n_iter, int norm, void* ws, hipStream_t st) {
     float* hh = (float*)((char*)history + FRONT_PAD);
     (void)ws;
-    return tsw2d_pass(g, blur, blur, sparse, out, B, H, W, norm, st, hh);
+    if (int e = tsw2d_pass(g, blur, blur, sparse, out, B, H, W, norm, st, hh)) return e;   // (n_iter < 24: `out` = level 24 for a moment)
+    const int nseg = n_iter / CK;
+    if (nseg <= NCKP) {   // the result is the checkpoint H_n
+        reg_to_img_plane(hh + (size_t)(nseg - 1) * B * H * W, out, (size_t)B * H * W, st);
+        return check_launch("reg_to_img_plane_kernel");
+    }
+    return 0;
 }
 
 size_t backward2d_history_workspace(int B, int H, int W) {
@@ -920,14 +942,16 @@ size_t backward2d_history_workspace(int B, int H, int W) {
 }
 
 int backward2d_history(const float* g, const float* blur, const float* sparse, const float* gout, const void* history, float* gg,
-                       float* gb, int B, int H, int W, int norm, void* ws, hipStream_t st) {
+                       float* gb, int B, int H, int W, int n_iter, int norm, void* ws, hipStream_t st) {
     const size_t total = (size_t)B * H * W;
     const float* hh = (const float*)((const char*)history + FRONT_PAD);
     const float* wf = hh + NCKP * total;
     float* ah = (float*)ws;
     float* a0 = ah + NCKP * total;
+    const int nseg = n_iter / CK;
     if (int e = tsw2d_adjoint_pass(wf, gout, a0, B, H, W, st, ah)) return e;
-    launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, st);
+    if (nseg <= NCKP) reg_to_img_plane(ah + (size_t)(nseg - 1) * total, a0, total, st);
+    launch_final_ck(g, blur, sparse, hh, ah, wf, a0, gout, gg, gb, B, H, W, norm, nseg, st);
     return check_launch("bwd_final_ck_kernel");
 }
 

@@ -163,7 +163,7 @@ int cspn2d_forward_history_f32(const float* guidance, const float* blur, const f
     if (!history || history_bytes < hb || ((uintptr_t)history & 255u)) { set_error("history buffer too small or misaligned: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
     if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, fused2d_workspace(B, H, W, n_iter))) return e;
     if (((uintptr_t)out & 15u) != 0) { set_error("output must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
-    return forward2d_history(guidance, blur, sparse, out, history, B, H, W, norm_type, ws, (hipStream_t)stream);
+    return forward2d_history(guidance, blur, sparse, out, history, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream);
 }
 
 size_t cspn2d_backward_history_workspace_bytes(int B, int H, int W, int n_iter) {
@@ -181,7 +181,7 @@ int cspn2d_backward_history_f32(const float* guidance, const float* blur, const 
     if (!history || history_bytes < hb) { set_error("history buffer too small: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
     if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_history_workspace(B, H, W))) return e;
     if (!grad_guidance && !grad_blur) return 0;
-    return backward2d_history(guidance, blur, sparse, grad_out, history, grad_guidance, grad_blur, B, H, W, norm_type, ws,
+    return backward2d_history(guidance, blur, sparse, grad_out, history, grad_guidance, grad_blur, B, H, W, n_iter, norm_type, ws,
                               (hipStream_t)stream);
 }
 

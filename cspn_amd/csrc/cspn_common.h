@@ -107,9 +107,9 @@ int backward2d(const float* g, const float* blur, const float* sparse, const flo
 // kernel takes), the backward starts there
 size_t history2d_bytes(int B, int H, int W, int n_iter);  // 0: not available for this shape
 int forward2d_history(const float* g, const float* blur, const float* sparse, float* out, void* history, int B, int H, int W,
-                      int norm, void* ws, hipStream_t st);
+                      int n_iter, int norm, void* ws, hipStream_t st);
 size_t backward2d_history_workspace(int B, int H, int W);
 int backward2d_history(const float* g, const float* blur, const float* sparse, const float* gout, const void* history, float* gg,
-                       float* gb, int B, int H, int W, int norm, void* ws, hipStream_t st);
+                       float* gb, int B, int H, int W, int n_iter, int norm, void* ws, hipStream_t st);
 
 }  // namespace cspn

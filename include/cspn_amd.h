@@ -113,14 +113,15 @@ int cspn2d_forward_prenorm_f32(const float* wb, const float* blur, const float* 
  *   grad_out      [B,1,H,W]  dL/d(out)
  *   grad_guidance [B,8,H,W]  dL/d(guidance), or NULL to skip
  *   grad_blur     [B,1,H,W]  dL/d(blur_depth) (as level-0 value and as H_0 of the centre / mask terms), or NULL to skip
- * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1. */
+ * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1.  Fast path (two sweeps of the assembly ring that keep every fourth
+ * level + one recomputing final pass): W >= 256, W % 4 == 0, n_iter = 4, 8 .. 24 (24 only until round 5); everything else runs one launch per step. */
 size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter);
 int cspn2d_backward_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
                         float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type,
                         void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 /* Training mode (optional, faster): the forward also keeps what the backward needs -- every fourth intermediate level (H_4, H_8 ..
- * H_20; the backward recomputes the three in between) and the folded coefficients, 13 planes of B*H*W floats, cspn2d_history_bytes() bytes, 256-B aligned; 0 = not available for this shape / n_iter (then use
+ * H_20; the backward recomputes the three in between) and the folded coefficients, 13 planes of B*H*W floats, cspn2d_history_bytes() bytes, 256-B aligned; 0 = not available for this shape / n_iter (available: W >= 256, W % 4 == 0, n_iter = 4, 8 .. 24; else use
  * cspn2d_forward_f32 + cspn2d_backward_f32, which recomputes the history).  This is what torch autograd does for the
  * reference by saving ~27 temporaries per iteration.
  *   cspn2d_forward_history_f32: same result as cspn2d_forward_f32, plus `history`; workspace cspn2d_workspace_bytes().

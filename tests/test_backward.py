@@ -70,7 +70,11 @@ def test_hip_backward_vs_reference_autograd_goldens():
                                              # the checkpointed final pass at awkward tile geometry: one tile row and a bit, a last
                                              # tile column of 8 pixels, image borders inside every block
                                              (2, 41, 260, 24, "8sum", True), (1, 89, 300, 24, "8sum_abs", False),
-                                             (1, 3, 256, 24, "8sum", False)])   # an image lower than the recompute halo
+                                             (1, 3, 256, 24, "8sum", False),    # an image lower than the recompute halo
+                                             # round 5: n_iter = 4, 8 .. 20 on the checkpointed ring path too (the sweeps run their 24 levels,
+                                             # H_n / A_0 are checkpoint planes, the final pass runs n_iter / 4 segments)
+                                             (2, 41, 260, 4, "8sum", True), (1, 70, 304, 8, "8sum_abs", False), (2, 33, 516, 16, "8sum", True),
+                                             (1, 50, 256, 20, "8sum_abs", True)])
 def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
     import cspn_amd
     g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp)
@@ -90,10 +94,11 @@ def test_hip_backward_vs_oracle_and_through_autograd(B, H, W, N, norm, sp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm,sp", [("8sum", True), ("8sum_abs", False)])
-def test_training_mode_history_matches_recompute_path(norm, sp):
+@pytest.mark.parametrize("N", [24, 12])
+def test_training_mode_history_matches_recompute_path(norm, sp, N):
     """the forward that keeps its checkpoints + the backward that starts from them == plain forward + recomputing backward"""
     import cspn_amd
-    B, H, W, N = 3, 70, 512, 24
+    B, H, W = 3, 70, 512
     assert cspn_amd.cspn2d_history_bytes(B, H, W, N) > 0 and cspn_amd.cspn2d_history_bytes(B, H, 64, N) == 0
     g, h, s = make_inputs(B, H, W, seed=21, sparse=sp, neg=sp)
     go = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(6)).cuda()

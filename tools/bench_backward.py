@@ -48,10 +48,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--vol3d", action="store_true", help="the 3D backward (Paddle contract) at BASELINE config 5's volume")
+    ap.add_argument("--n-iter", type=int, default=24, help="2D: iterations (multiples of 4 up to 24 take the checkpointed ring path)")
     a = ap.parse_args()
     if a.vol3d:
         return vol3d(a)
-    B, H, W, N = a.batch, 304, 1216, 24
+    B, H, W, N = a.batch, 304, 1216, a.n_iter
     gen = torch.Generator(device="cuda").manual_seed(1)
     g = torch.randn(B, 8, H, W, generator=gen, device="cuda")
     h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
