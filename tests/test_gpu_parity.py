@@ -783,16 +783,24 @@ def test_forward_paths_can_be_captured_in_a_graph():
     cspn_amd.cspn2d_forward(g, h, None, 24, "8sum"); cspn_amd.cspn3d_forward(g3, h3, None, 6, "none")   # warm the allocator
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
+    gw, hw = g[..., :510].contiguous(), h[..., :510].contiguous()   # W % 4 != 0: the padded path (five launches)
+    cspn_amd.cspn2d_forward(g, h, None, 31, "8sum"); cspn_amd.cspn2d_forward(gw, hw, None, 24, "8sum")
+    torch.cuda.synchronize()
     with torch.cuda.graph(graph):
         o2 = cspn_amd.cspn2d_forward(g, h, None, 24, "8sum")
+        o2s = cspn_amd.cspn2d_forward(g, h, None, 31, "8sum")        # round 5: a short first pass of 7 iterations + a full pass
+        o2w = cspn_amd.cspn2d_forward(gw, hw, None, 24, "8sum")
         o3 = cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="persistent")
     for seed in (1, 2):
         gen2 = torch.Generator(device="cuda").manual_seed(seed)
         h.copy_(torch.rand(2, 1, 96, 512, generator=gen2, device="cuda") * 10)
+        hw.copy_(h[..., :510])
         h3.copy_(torch.rand(1, 1, 16, 24, 128, generator=gen2, device="cuda"))
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(o2, cspn_amd.cspn2d_forward(g, h, None, 24, "8sum"))
+        assert torch.equal(o2s, cspn_amd.cspn2d_forward(g, h, None, 31, "8sum"))
+        assert torch.equal(o2w, cspn_amd.cspn2d_forward(gw, hw, None, 24, "8sum"))
         assert torch.equal(o3, cspn_amd.cspn3d_forward(g3, h3, None, 6, "none", algo="stepwise"))
 
 
