@@ -582,19 +582,22 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
         // the last pass writes `out`; earlier passes alternate so that no pass reads what it writes
         float* dst = ((passes - 1 - p) % 2 == 0) ? out : pingpong;
         if (asm_ok && n < LV) {
-            if (int e = tsw2d_pass(g, blur, blur, sparse, dst, B, H, W, norm, st, nullptr, plan_mode, n)) return e;
+            if (int e = tsw2d_pass(g, blur, blur, sparse, dst, B, H, W, norm, st, nullptr, plan_mode & 7, n)) return e;
             hin = dst;
             done += n;
             continue;
         }
         if (asm_ok && n == LV) {
 #ifdef CSPN_EXPERIMENTS
-            if (plan_mode == 3) {   // the round-3 loop (experiment builds only)
+            if ((plan_mode & 7) == 3) {   // the round-3 loop (experiment builds only)
                 if (!tsw3_supported(B, H, W, sparse != nullptr, hin != blur)) { set_error("round-3 loop: unsupported call"); return CSPN_E_UNSUPPORTED; }
                 if (int e = tsw3_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
             } else
 #endif
-            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st, nullptr, plan_mode)) return e;
+            if (hin == blur && !(plan_mode & 8) && tsw4_supported(B, H, W)) {   // round 6: 12 waves x 3 rows, three waves per SIMD
+                if (int e = tsw4_pass(g, blur, sparse, dst, B, H, W, norm, st, plan_mode)) return e;
+            } else
+            if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st, nullptr, plan_mode & 7)) return e;
             hin = dst;
             done += n;
             continue;

@@ -78,7 +78,8 @@ int backward3d(const float* g, const float* feat, const float* gout, float* gg, 
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);
-// plan_mode (test-hook library only; the ABI passes 0): 0 the linear plan, 1 the same without XCD-aware placement, 2 band groups
+// plan_mode (test-hook library only; the ABI passes 0): 0 the linear plan, 1 the same without XCD-aware placement, 2 band groups;
+// + 8: the 8-wave x 4-row loop of rounds 1-5 (cspn2d_tsw.hip) also for the passes the round-6 loop (cspn2d_tsw4.hip) would take
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
                     int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true, int plan_mode = 0);
 
@@ -87,6 +88,11 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
 bool tsw2d_supported(int B, int H, int W);
 int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float* sparse, float* out, int B, int H,
                int W, int norm, hipStream_t st, float* hist = nullptr, int plan_mode = 0, int n_early = 0);
+// ---- round 6: the same ring as 12 waves x 3 rows at 168 VGPRs -- three waves per SIMD (cspn2d_tsw4.hip, tools/tswgen/kernel4.py): FIRST
+// passes of exactly 24 iterations ----
+bool tsw4_supported(int B, int H, int W);
+int tsw4_pass(const float* gd, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm, hipStream_t st,
+              int plan_mode = 0);
 #ifdef CSPN_EXPERIMENTS
 // ---- experiments kept out of the default build (make EXPERIMENTS=1): the round-3 loop (cspn2d_tsw3.hip: LDS-DMA row slots;
 // ties with the loop above on long streams, slower on short ones: profiles/r03_perf_notes.md) and the sited8 guidance layout ----
