@@ -90,7 +90,7 @@ TSW4_VARIANT(3, 1)
 
 #ifdef TSW4_TRACE
 __device__ char* g_tsw4_trace = nullptr;
-constexpr size_t TSW4_TRACE_WG_BYTES = 1024 * TSW4_NW * 16;
+constexpr size_t TSW4_TRACE_WG_BYTES = 1024 * TSW4_NW * 32;
 #endif
 
 // the step in which stream row Q - 1 retires (tools/tswgen/kernel4.py last_step): row q enters at step 2 (q div 3) + q mod 3

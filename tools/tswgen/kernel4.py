@@ -96,7 +96,8 @@ S_SL3 = [S(62), S(63), S(64)]                   # LDS address of the slot group 
 S_RT, S_RB = S(65), S(66)                       # LDS address (buffer 0, lane 0) of the row above / below this wave's rows
 T = [S(68 + i) for i in range(12)]
 S_GDK = [S(80 + 2 * k, 2) for k in range(8)]    # guidance base + plane k's (sited) offset
-TRACE_REGS = [S(96, 2), S(98, 2)]
+TRACE_REGS = [S(48, 2), S(50, 2), S(96, 2), S(98, 2)]   # cfg trace: s_memtime stamps of a step
+TRACE_BYTES = 32
 
 
 class Gen(object):
@@ -121,17 +122,29 @@ class Gen(object):
             roles[4 + 2 * t]["cook"] = (1, t)
             roles[3 + 2 * t]["cook"] = (2, t)
             roles[11 + 2 * t]["cook"] = (3, t)
-        for pc in range(npc):                       # even steps: one piece per wave (c = 4 .. 22)
-            roles[4 + 2 * pc]["dma"].append((7, pc))
-        for pc in range(4):                         # odd steps: the cooking waves one piece each, three others the rest
-            roles[3 + 2 * pc]["dma"].append((8, pc))
-            roles[11 + 2 * pc]["dma"].append((9, pc))
-        for pc in range(4, 8):
-            roles[19]["dma"].append((8, pc))
-            roles[21]["dma"].append((9, pc))
-        for pc in range(8, npc):
-            roles[23]["dma"].append((8, pc))
-            roles[23]["dma"].append((9, pc))
+        if self.cfg.get("roles", 2) == 1:               # first version (profiles/r06_*: c = 2 waited for its own store)
+            for pc in range(npc):                       # even steps: one piece per wave (c = 4 .. 22)
+                roles[4 + 2 * pc]["dma"].append((7, pc))
+            for pc in range(4):                         # odd steps: the cooking waves one piece each, three others the rest
+                roles[3 + 2 * pc]["dma"].append((8, pc))
+                roles[11 + 2 * pc]["dma"].append((9, pc))
+            for pc in range(4, 8):
+                roles[19]["dma"].append((8, pc))
+                roles[21]["dma"].append((9, pc))
+            for pc in range(8, npc):
+                roles[23]["dma"].append((8, pc))
+                roles[23]["dma"].append((9, pc))
+        else:
+            # no requests at c = 21 .. 23: the wait for them would fall into the event steps c = 0 .. 2, whose retirement stores share
+            # the vmcnt counter.  Even steps: c = 4 .. 20 (nine waves) one piece each, the tenth (mask) with c = 20's.  Odd steps: the
+            # cooking waves c = 3 .. 17 two pieces each, c = 19 the rest
+            for pc in range(npc):
+                roles[min(4 + 2 * pc, 20)]["dma"].append((7, pc))
+            for i in range(4):
+                roles[3 + 2 * i]["dma"] += [(8, 2 * i), (8, 2 * i + 1)]
+                roles[11 + 2 * i]["dma"] += [(9, 2 * i), (9, 2 * i + 1)]
+            for pc in range(8, npc):
+                roles[19]["dma"] += [(8, pc), (9, pc)]
         if "nocook" in self.ab:
             for r in roles.values():
                 r["cook"] = None
@@ -296,9 +309,11 @@ class Gen(object):
             self.p.label(".LS%d_%%=" % c)
             if act_fast:
                 self.e("s_cbranch_vccnz", (), [".LSs%d_%%=" % c])
-        prio = self.cfg.get("prio", 1) if ev is not None else 0
+        prio = self.cfg.get("prio", 1) if ev is not None else (self.cfg.get("cook_prio", 2) if cook else 0)
         if prio:
             self.e("raw", (), ["s_setprio %d" % prio])
+        self.probe(0)
+        trace = self.cfg.get("trace", False)
         hn, ha = (HN, HA) if (ev is None or ev % 2 == 0) else (HA, HN)
         # ---- top: everything that travels through LDS is requested first
         if p == 0:
@@ -329,18 +344,28 @@ class Gen(object):
                 self.ring_read(WT(0, k), 0, k, at=0.0)
             if "noevlds" not in self.ab:
                 n_after += len(self.early_planes(0))
-        self.p.waitcnt(lgkm=min(n_after, 15) if ev is not None else 0)
-        self.probe(0)
+        n_cook = 0
+        if cook and self.cfg.get("cook_partial", True) and not trace and "nocookread" not in self.ab:
+            n_cook = 9 + (1 if self.sparse else 0)     # the raw reads were requested last (behind the flags and the DMA roles' descriptors)
+        self.p.waitcnt(lgkm=min(n_after, 15) if (ev is not None and not trace) else n_cook)
+        self.probe(1)
         if dma:
             self.dma_issue(c, dma, fetched)
         if cook:
-            self.cook_math(c, *cook)
-            self.cook_writes(c, *cook)
+            self._cook_pending = (c,) + tuple(cook) if n_cook else None
+            if not n_cook:
+                self.cook_math(c, *cook)
+                self.cook_writes(c, *cook)
         # received boundary rows
         self.shift(BQ, D_BQ)
         self.push_below(NSLOT - 1, BQ, D_BQ, N1[NSLOT - 1])
         self.shift(TQ, D_TQ)
         self.push_above(0, TQ, D_TQ, N1[0])
+        if cook and getattr(self, "_cook_pending", None):
+            self.p.waitcnt(lgkm=0)
+            self.cook_math(*self._cook_pending)
+            self.cook_writes(*self._cook_pending)
+            self._cook_pending = None
         for j in range(NSLOT - 1, -1, -1):
             vq = N1[j]
             tq = D_SLOT.get(j)
@@ -369,7 +394,7 @@ class Gen(object):
                 self.push_self(j, vq, tq, N2[j])
             if j < NSLOT - 1:
                 self.push_above(j + 1, vq, tq, N1[j + 1], init=WT(j + 1, 8))
-        self.probe(1)
+        self.probe(2)
         if prio:
             self.e("raw", (), ["s_setprio 0"])
         # the pieces this wave requested three steps ago are cooked in the next step: they must have landed before this step's barrier
@@ -378,6 +403,7 @@ class Gen(object):
             self.p.waitcnt(vm=min(nd(c - 2) + nd(c - 1) + nd(c), 63), lgkm=0)
         else:
             self.p.waitcnt(lgkm=0)
+        self.probe(3)
         if "nobar" not in self.ab:
             self.e("s_barrier")
         self.trace_flush(c)
@@ -387,20 +413,21 @@ class Gen(object):
             self.e("s_branch", (), [".LS%d_%%=" % ((c + 1) % LV)])
 
     def trace_flush(self, c):
+        """cfg trace: the step's four stamps (low dwords) + the ring counter -> 32 bytes per wave and step (tools/r06/tsw4_trace.py)"""
         if not self.cfg.get("trace", False):
             return
         e = self.e
-        for k, r in enumerate(TRACE_REGS):
-            e("raw", (), ["v_writelane_b32 v7, s%d, %d" % (r.i, k)])
-        e("raw", (), ["s_memtime s[%d:%d]" % (TRACE_REGS[0].i, TRACE_REGS[0].i + 1)])
         e("raw", (), ["s_waitcnt lgkmcnt(0)"])
-        e("raw", (), ["v_writelane_b32 v7, s%d, 2" % TRACE_REGS[0].i])
+        for k, r in enumerate(TRACE_REGS):
+            e("raw", (), ["v_writelane_b32 v9, s%d, %d" % (r.i, k)])
         e("raw", (), ["s_movk_i32 s%d, %d" % (T[0].i, c)])
-        e("raw", (), ["v_writelane_b32 v7, s%d, 3" % T[0].i])
-        e("raw", (), ["s_mov_b64 exec, 0xf"])
-        e("raw", (), ["global_store_dword v6, v7, s[26:27]"])
+        e("raw", (), ["v_writelane_b32 v9, s%d, 4" % T[0].i])
+        e("raw", (), ["s_lshl_b32 s%d, s%d, 5" % (T[0].i, S_WV.i)])
+        e("raw", (), ["v_add_u32_e32 v8, s%d, v1" % T[0].i])
+        e("raw", (), ["s_mov_b64 exec, 0x1f"])
+        e("raw", (), ["global_store_dword v8, v9, s[26:27]"])
         e("raw", (), ["s_mov_b64 exec, -1"])
-        e("raw", (), ["s_add_u32 s26, s26, %d" % (NW * 16)])
+        e("raw", (), ["s_add_u32 s26, s26, %d" % (NW * TRACE_BYTES)])
         e("raw", (), ["s_addc_u32 s27, s27, 0"])
 
     # ---------------------------------------------------------------------------------- DMA of raw rows
@@ -677,10 +704,6 @@ class Gen(object):
         e("s_add_i32", S_QTA, [S_TABB, (3 * (-LEAD // 2) - 3) * DESC_BYTES])   # counted up by the first (even) step
         self.p.waitcnt(lgkm=0)
         e("s_barrier")
-        if self.cfg.get("trace", False):
-            e("s_mul_i32", T[3], [S_WV, 16])
-            e("v_lshlrev_b32", V(6), [2, V_LANE])
-            e("v_add_u32", V(6), [T[3], V(6)])
         for w in range(NW):
             c0 = (-LEAD - 2 * w) % LV
             e("s_cmp_eq_u32", (), [S_WV, w])
