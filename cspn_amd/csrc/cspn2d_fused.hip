@@ -594,7 +594,7 @@ int fused2d_forward(const float* g, const float* blur, const float* sparse, floa
                 if (int e = tsw3_pass(g, blur, hin, sparse, dst, B, H, W, norm, st)) return e;
             } else
 #endif
-            if (hin == blur && !(plan_mode & 8) && tsw4_supported(B, H, W)) {   // round 6: 12 waves x 3 rows, three waves per SIMD
+            if (hin == blur && !(plan_mode & 8) && ((plan_mode & 16) ? tsw4_supported(B, H, W) : tsw4_preferred(B, H, W, sparse != nullptr))) {   // round 6: 12 waves x 3 rows, three waves per SIMD
                 if (int e = tsw4_pass(g, blur, sparse, dst, B, H, W, norm, st, plan_mode)) return e;
             } else
             if (int e = tsw2d_pass(g, blur, hin, sparse, dst, B, H, W, norm, st, nullptr, plan_mode & 7)) return e;

@@ -155,6 +155,17 @@ TSW4_DEF(3)
 // A FIRST pass of exactly 24 iterations (level 0 = blur) over images at least one band wide
 bool tsw4_supported(int B, int H, int W) { return tsw2d_supported(B, H, W); }
 
+// Where the 12 x 3 ring pays (profiles/r06_ring_ab_sweep.md, MI355X): its six lead-in steps and its longer prologue cost 5 .. 17 % on
+// short streams, from ~190 stream rows per workgroup on it is 1 .. 3 % faster than the 8 x 4 ring (with a mask: from ~420 rows).  Only on
+// the linear plan (one piece per CU; a table that does not fit this loop's LDS falls back to band groups: the 8 x 4 ring takes those).
+bool tsw4_preferred(int B, int H, int W, bool sparse) {
+    if (!tsw4_supported(B, H, W)) return false;
+    const PlanGeo& g = tswplan::make_geo_linear(B, H, W, TSW4_PADF, TSW4_PADB, TSW4_TAB_MAX_ROWS, 0);
+    if (g.kind != 1) return false;
+    const int longest = g.stride - TSW4_PADF - TSW4_PADB;
+    return longest >= (sparse ? 420 : 190);
+}
+
 int tsw4_pass(const float* gd, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm, hipStream_t st, int plan_mode) {
     // the linear plan of the forward passes (cspn2d_tsw_plan.h: one piece per CU, cuts where the longest stream is shortest); band
     // groups with more workgroups than CUs when a piece's table would not fit this loop's LDS

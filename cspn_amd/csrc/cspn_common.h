@@ -79,7 +79,8 @@ int backward3d(const float* g, const float* feat, const float* gout, float* gg, 
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);
 // plan_mode (test-hook library only; the ABI passes 0): 0 the linear plan, 1 the same without XCD-aware placement, 2 band groups;
-// + 8: the 8-wave x 4-row loop of rounds 1-5 (cspn2d_tsw.hip) also for the passes the round-6 loop (cspn2d_tsw4.hip) would take
+// + 8: the 8-wave x 4-row loop of rounds 1-5 (cspn2d_tsw.hip) also for the passes the round-6 loop (cspn2d_tsw4.hip) would take;
+// + 16: the round-6 loop for every full first pass it supports (also the short streams on which the dispatcher prefers the other)
 int fused2d_forward(const float* g, const float* blur, const float* sparse, float* out, int B, int H, int W,
                     int n_iter, int norm, void* ws, hipStream_t st, bool use_asm = true, int plan_mode = 0);
 
@@ -91,6 +92,7 @@ int tsw2d_pass(const float* gd, const float* blur, const float* hin, const float
 // ---- round 6: the same ring as 12 waves x 3 rows at 168 VGPRs -- three waves per SIMD (cspn2d_tsw4.hip, tools/tswgen/kernel4.py): FIRST
 // passes of exactly 24 iterations ----
 bool tsw4_supported(int B, int H, int W);
+bool tsw4_preferred(int B, int H, int W, bool sparse);   // long streams on the linear plan: where it is the faster of the two rings
 int tsw4_pass(const float* gd, const float* blur, const float* sparse, float* out, int B, int H, int W, int norm, hipStream_t st,
               int plan_mode = 0);
 #ifdef CSPN_EXPERIMENTS

@@ -31,7 +31,7 @@ def _algos(B, H, W, N):
 def _forward(g, h, s, N, norm, algo):
     """cspn2d_forward; 'fused_groups' / 'fused_noxcd' = algo 'fused' with the assembly passes on the band-group plan of rounds
     1-3 / on the linear plan without XCD-aware placement (hook library: the plan is an argument of an internal entry point)"""
-    mode = {"fused_noxcd": 1, "fused_groups": 2}.get(algo)
+    mode = {"fused_noxcd": 1, "fused_groups": 2, "fused_ring8": 8, "fused_ring12": 16, "fused_ring12_noxcd": 17}.get(algo)   # + 8 / + 16: the 8 x 4 / the 12 x 3 ring
     if mode is None:
         return cspn_amd.cspn2d_forward(g, h, s, N, norm, algo)
     hooks = _lib.load_hooks()
@@ -218,8 +218,8 @@ def test_benchmarked_shape_b64(sparse):
     g, h, s = config_inputs(B, H, W, 80.0, sparse)
     gd, hd = g.to(DEV), h.to(DEV)
     sd = s.to(DEV) if sparse else None
-    outs = {a: _forward(gd, hd, sd, 24, "8sum", a) for a in ("stepwise", "fused", "fused_cxx", "fused_groups", "fused_noxcd")}
-    torch.cuda.synchronize()
+    outs = {a: _forward(gd, hd, sd, 24, "8sum", a) for a in ("stepwise", "fused", "fused_cxx", "fused_groups", "fused_noxcd", "fused_ring8", "fused_ring12")}
+    torch.cuda.synchronize()   # ("fused" = the dispatcher's choice: round 6's 12 x 3 ring at this stream length; both rings explicitly)
     _pairwise_whole_batch(outs, "b64")
     info = _plan_info(B, H, W)
     assert info["kind"] == 1 and info["n_wg"] == 256 and info["xcd"] == 1 and info["kimg"] == 3, info   # the plan DESIGN.md describes
@@ -507,8 +507,8 @@ def test_asm_loop_parity_vs_oracle(B, H, W, N, norm, sp):
     if H > 20:
         g[0, :, 9:12, 100:108] = 0.0  # 0/0 -> NaN patch must spread exactly like the reference's (cspn.py:138)
     ref = cspn2d_oracle(g, h, s, N, norm)
-    outs = {a: _run(g, h, s, N, norm, a) for a in ("fused", "fused_cxx", "fused_groups", "fused_noxcd")}
-    for a, o in outs.items():
+    outs = {a: _run(g, h, s, N, norm, a) for a in ("fused", "fused_cxx", "fused_groups", "fused_noxcd", "fused_ring8", "fused_ring12", "fused_ring12_noxcd")}
+    for a, o in outs.items():   # (round 6: full first passes on both rings, whichever the dispatcher would pick for the shape)
         assert_close_tight(o, ref, a)
 
 

@@ -44,7 +44,7 @@ def run(cases=40, seed=1, verbose=True):
       h = torch.rand(B, 1, H, W, generator=gen, device="cuda") * 80
       s = (torch.rand(B, 1, H, W, generator=gen, device="cuda") < 0.02).float() * (h + 0.1) if sp else None
       b = cspn_amd.cspn2d_forward(g, h, s, N, norm, "stepwise")
-      for loop in (0, 2):   # the product's linear plan and the band-group plan (which the history / adjoint variants still use)
+      for loop in (0, 2, 8, 16, 18):   # the product's dispatch / the band-group plan; + 8: the 8 x 4 ring, + 16: the round-6 12 x 3 ring for every full first pass
           a = forward2d_plan(g, h, s, N, norm, loop)
           assert torch.equal(torch.isnan(a), torch.isnan(b)), ("2D nan", loop, B, H, W, norm, sp, N)
           err = float(((a - b).abs().nan_to_num()).max() / b.abs().nan_to_num().max().clamp_min(1e-30))

@@ -465,6 +465,10 @@ class Gen(object):
             e("v_readfirstlane_b32", S_DD[i], [HN[i]])
         grp, off = self.slot_of(c, d)
         n = self.npieces
+        if "sameload" in self.ab:      # timing experiment: every request reads the same (cache-resident) rows
+            e("s_mov_b32", S_DD[0], [0])
+            e("s_mov_b32", S_DD[1], [0])
+            e("s_mov_b32", S_DD[2], [0])
         for pc in range(n):
             P = S_P[pc % 4]
             if pc < 8:
