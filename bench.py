@@ -33,14 +33,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# ---- the printed line stays below the driver's 8 KB tail: prose lives in profiles/bench_legend.json (this table, written by
+# `python bench.py --write-legend`, checked by tests/test_bench_line.py), the line carries "@code" references and numbers ----
+LEGEND = {
+    "oracle": "oracle/cspn_oracle.c: C restatement of reference cspn_pytorch/models/cspn.py:42-172, pinned to golden vectors produced by the unmodified "
+              "reference (tests/golden/cspn2d_golden.npz); run AFTER the timed region on a sample of what the timed launches left in `out`",
+    "oracle_bwd": "oracle/backward.py, pinned to the reference's autograd gradients (tests/golden/cspn2d_grad_golden.npz)",
+    "data2d": "synthetic: randn affinity, uniform depth * scale; image i of the global batch from torch.Generator().manual_seed(1000 + i) on the CPU "
+              "(SURVEY 8d), copied to HBM before the timed region",
+    "data3d": "synthetic: uniform gates normalised over the 26 channels, uniform feature volume; generated on device",
+    "k_tsw4": "cspn2d_tsw4_kernel: gfx950 assembly main loop, round 6: a ring of 12 waves x 3 rows at 168 VGPRs (3 waves per SIMD), rows by LDS-DMA; ONE "
+              "launch per forward, every workgroup builds the row stream of its piece of the linear plan in LDS, nothing else runs in the timed region",
+    "k_tsw": "cspn2d_tsw_kernel: gfx950 assembly main loop, the 8 waves x 4 rows ring of rounds 1-5; ONE launch per forward (same plan)",
+    "k_tsw_short": "cspn2d_tsw_kernel: a short first pass of n_iter % 24 iterations (+ n_iter // 24 passes of 24) of the 8 x 4 ring",
+    "k_padded": "normalize2d_pitch_kernel / pad_rows_kernel -> the fused path on rows padded to a multiple of 4 columns -> unpad_rows_kernel (whole forward)",
+    "k_fused_cxx": "cspn2d_fused_kernel (compiler-generated ring kernel, one launch per forward)",
+    "k_stepwise": "fold2d_kernel + n_iter x step2d_kernel (whole forward)",
+    "k_prenorm": "the dispatcher's ring kernel, norm 3 (CSPN_NORM_PRENORM): the guidance planes are the reference's gate_wb (cspn.py:85-144), cooking reduced to "
+                 "sigma = sum w, c' = (1 - sigma) H0; same 40 B/pixel",
+    "k_bwd": "one cspn2d_backward_f32 call: cspn2d_tsw_kernel history sweep + adjoint sweep + bwd_final_mx_kernel, back to back inside the event pair "
+             "(per call, not per kernel)",
+    "k_p3": "cspn3d_persistent_kernel: one launch per forward, gates read once and resident in registers for all steps; algorithmic bytes = 26 gates + value in, "
+            "value out = 112 B/voxel ONCE per forward (SURVEY 8d)",
+    "k_step3d": "step3d_direct_kernel: one launch per iteration (112 B/voxel each); whole_forward_frac prices all iterations against a single pass over the inputs",
+    "field_traffic": "`traffic` / `traffic_key`: HBM-side bytes per launch from separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; the entry `traffic_key` of "
+               "profiles/pmc_traffic.json names the profile it comes from and the gfx950 corrections applied",
+    "unpinned3d": "the Paddle op's source is not in the reference tree: 3D parity is UNPINNED; the two HIP paths are compared on every voxel and with "
+                  "oracle/cspn_oracle.c on one full 32x160x608 volume",
+    "cpu_port": "kind port = oracle/cspn_oracle.c (the C restatement of reference cspn.py, OpenMP over images, one image per thread) on the host's threads: NOT the "
+                "reference's own code path; /root/reference does not exist on the GPU box",
+    "cpu_refops": "the reference's OWN path on the CPU: tools/torch_ops_baseline.py = the torch op sequence reference cspn.py:42-83 launches (eight padded copies + "
+                  "cat, product, 1x1x1 Conv3d channel sum, per iteration), pinned to the unmodified reference's golden vectors (tests/test_oracle.py); ONE image per "
+                  "forward on torch-CPU in a child process at 16 / 64 / physical-core thread counts; `value` = the fastest that ran, `physical_cores` = "
+                  "torch.set_num_threads(number of physical cores)",
+    "cfg1": "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)",
+    "cfg2": "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304, batch 16 on one GPU",
+    "cfg3": "BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216 (batch 64 sharded over 8 GPUs as written: 8 per GPU; the headline runs 64 per GPU)",
+    "cfg4": "BASELINE config 4: 2D CSPN 3x3 + sparse-depth replacement (500-point mask), 24 iters, KITTI 304x1216, batch 32 on one GPU",
+    "cfg5": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 cost volume, batch 4 on one GPU; gates pre-normalised by the caller (Paddle contract)",
+    "bwd": "cspn2d_backward_f32: gradient of BASELINE config 3's forward w.r.t. guidance and blur_depth (reference train.py:196-198), 76 B/pixel algorithmic",
+}
 BACKBONE_PARAMS = 256_078_272  # resnet50-CSPN fp32 parameter count (probed)
 
 WORKLOADS = {
     # name: (H, W, n_iter, sparse, depth scale, description)
-    "kitti": (304, 1216, 24, False, 80.0, "BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216"),
-    "kitti_sparse": (304, 1216, 24, True, 80.0, "BASELINE config 4: 2D CSPN 3x3 + sparse-depth replacement (500-pt mask), 24 iters, 304x1216"),
-    "nyu": (228, 304, 24, True, 10.0, "BASELINE config 2: 2D CSPN 3x3, 24 iters, NYUv2 228x304"),
-    "plumbing": (228, 304, 12, False, 10.0, "BASELINE config 1: 2D CSPN 3x3, 12 iters, 1x1x228x304 (the reference's CPU-runnable plumbing case)"),
+    "kitti": (304, 1216, 24, False, 80.0, "@cfg3"),
+    "kitti_sparse": (304, 1216, 24, True, 80.0, "@cfg4"),
+    "nyu": (228, 304, 24, True, 10.0, "@cfg2"),
+    "plumbing": (228, 304, 12, False, 10.0, "@cfg1"),
     # off the fast path (round-4 review, weak 8): measured for the record, not part of the driver's line
     "kitti_n12": (304, 1216, 12, False, 80.0, "KITTI 304x1216, 12 iterations (BASELINE config 1's count; the reference's own defaults are 24, cspn_paddle/demo.py:92): one short pass of the assembly loop (round 5: a row is stored when it completes level 12)"),
     "kitti_w1218": (304, 1218, 24, False, 80.0, "304x1218 (W % 4 != 0), 24 iterations: rows padded to 1220 columns in the workspace, fused path on those (round 5; before: fold + one launch per iteration)"),
@@ -62,6 +103,7 @@ def parse():
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "fused", "fused_cxx", "fused_padded"])
     ap.add_argument("--norm-type", default="8sum", choices=["8sum", "8sum_abs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--write-legend", action="store_true", help="write profiles/bench_legend.json (the prose behind the line's @codes) and exit; no GPU needed")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="N = 1, default workload: do not also time BASELINE configs 4, 2, 3-as-written's per-GPU share, 5 and the 2D "
                          "backward after the headline's timed region (reported under \"configs\")")
@@ -127,7 +169,7 @@ def parity_check(out, g, h, s, n_iter, norm, rtol=1e-4):
     err = float(d.max() / scale) if fin.any() else 0.0
     elem_ok = bool((d <= 1e-6 * scale + rtol * ref[fin].abs()).all()) if fin.any() else True
     return {"ok": bool(err <= rtol and elem_ok), "images": idx, "max_rel_err": err, "rtol": rtol,
-            "against": "oracle/cspn_oracle.c (pinned to the reference's golden vectors)"}
+            "against": "@oracle"}
 
 
 _REFOPS_CHILD = r"""
@@ -148,7 +190,7 @@ for nthr in sorted({min(cores, 16), min(cores, 64), cores}):
     projected = t2 * (n_iter + 2.0) / 4.0
     left = budget - (time.perf_counter() - t_start)
     if projected > left:
-        print(json.dumps({"threads": nthr, "skipped": "a %d-iteration forward of ONE image projects to %.1f s (normalisation + 2 iterations took %.2f s); %.1f s of the leg's budget left" % (n_iter, projected, t2, left),
+        print(json.dumps({"threads": nthr, "skipped": "projects to %.1f s, %.1f s left" % (projected, left),
                           "projected_value": round(H * W * n_iter / 1e6 / projected, 2)}), flush=True)
         continue
     reps, t_total = 0, 0.0
@@ -181,18 +223,37 @@ def reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, cores, budget_s
     except Exception as ex:   # noqa: BLE001 -- reported in the line, never hidden
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     done = [x for x in legs if "value" in x]
-    allc = [x for x in legs if x["threads"] == cores]
+    allc = [x for x in legs if x["threads"] == cores]   # (`cores` = the host's PHYSICAL cores: see cpu_baseline)
     best = max(done, key=lambda x: x["value"]) if done else None
     out = {"unit": "Mpix*iters/s", "kind": "reference_op_sequence", "by_threads": legs,
-           "sample": "1 image %dx%d x %d iters per repetition, tools/torch_ops_baseline.py (the torch op sequence of reference cspn.py:42-83 "
-                     "incl. its 1x1x1 Conv3d channel sum, pinned to the unmodified reference's golden vectors) on torch-CPU %s in a child "
-                     "process; `value` / `cores` = the fastest thread count that ran, `all_cores` = torch.set_num_threads(os.cpu_count()) "
-                     "as SURVEY 8d prescribes" % (H, W, n_iter, torch.__version__)}
+           "what": "@cpu_refops", "image": [H, W], "n_iter": n_iter, "torch": torch.__version__.split("+")[0]}
     if best:
         out["value"], out["cores"] = best["value"], best["threads"]
     if allc:
-        out["all_cores"] = allc[0]
+        out["physical_cores"] = allc[0]
     return out
+
+
+def physical_cores():
+    """physical cores of the host (SMT siblings counted once): the thread count at which the reference's torch-CPU path is timed as "all cores"
+    (round-5 review: 256 torch threads on 128 cores oversubscribe the ~30 small ops per iteration)"""
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except Exception:   # noqa: BLE001
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
 def cpu_baseline(H, W, n_iter, sparse, scale, norm):
@@ -225,9 +286,8 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
         "unit": "Mpix*iters/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d images %dx%d x %d iters x %d reps, oracle/cspn_oracle.c (C port of reference cspn.py, OpenMP over images), host has %d cores"
-                  % (nimg, H, W, n_iter, reps, cores)
-                  + "; /root/reference (torch-CPU reference module) does not exist on the GPU box, so the C port stands in for it",
+        "what": "@cpu_port",
+        "sample": "%d images %dx%d x %d iters x %d reps; host threads %d" % (nimg, H, W, n_iter, reps, cores),
     }
     # the same port on 64 threads (rounds 1-4 capped it there: on this 256-thread host the memory-bound port is FASTER on 64)
     try:
@@ -237,11 +297,11 @@ def cpu_baseline(H, W, n_iter, sparse, scale, norm):
             cspn2d_oracle(g[:64], h[:64], None if s is None else s[:64], n_iter, norm)
             dt = time.perf_counter() - t0
             res["port_on_64_threads"] = {"value": round(64 * H * W * n_iter / 1e6 / dt, 2), "unit": "Mpix*iters/s", "cores": 64,
-                                         "sample": "64 images x %d iters, one repetition" % n_iter}
+                                         "sample": "64 images, 1 rep"}
             set_oracle_threads(cores)
     except Exception as ex:   # noqa: BLE001
         res["port_on_64_threads"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
-    res["reference_op_sequence"] = reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, cores)
+    res["reference_op_sequence"] = reference_op_sequence_cpu(H, W, n_iter, sparse, scale, norm, physical_cores())
     return res
 
 
@@ -296,8 +356,7 @@ def measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, st
         del other
         parity = {"ok": bool(err <= 1e-5 and eo <= 1e-4 and elem and torch.isfinite(out).all()), "max_rel_diff_between_3d_paths": err,
                   "oracle_full_volume": {"volume": vi, "voxels": D * H * W, "max_rel_err": eo, "rtol": 1e-4},
-                  "pinned": False, "note": "the Paddle op's source is not in the reference tree: parity unpinned; the two HIP "
-                  "paths are compared on every voxel and with oracle/cspn_oracle.c on one full 32x160x608 volume"}
+                  "pinned": False, "note": "@unpinned3d"}
     if dist is not None:
         t = torch.tensor([elapsed, dev_ms_avg], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,30 +368,28 @@ def measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, st
     fwd_frac = vox * 112 / (dev_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
     traffic, source = pmc_traffic("vol3d_B%d_%s" % (B, "persistent" if persistent else "stepwise"))
     if persistent:
-        roof = {"bound": "hbm", "kernel": "cspn3d_persistent_kernel (one launch per forward: gates read once, %d steps on chip)" % n_iter,
+        roof = {"bound": "hbm", "kernel": "@k_p3",
                 "achieved": round(vox * 112 / (dev_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(fwd_frac, 4), "traffic": traffic, "algorithmic_bytes_per_launch": vox * 112,
                 "device_ms_per_launch": round(dev_ms_avg, 4), "device_ms_min": round(dev_ms[0], 4), "whole_forward_frac": round(fwd_frac, 4),
-                "note": "algorithmic bytes = 26 gates + value in, value out = 112 B/voxel ONCE per forward (SURVEY 8d)"}
+                }
     else:
         launch_ms = dev_ms_avg / n_iter
-        roof = {"bound": "hbm", "kernel": "step3d_direct_kernel (one launch per iteration, %d per forward)" % n_iter,
+        roof = {"bound": "hbm", "kernel": "@k_step3d",
                 "achieved": round(vox * 112 / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(vox * 112 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": vox * 112, "device_ms_per_launch": round(launch_ms, 4),
-                "whole_forward_frac": round(fwd_frac, 4),
-                "note": "per launch = one propagation step (112 B/voxel); whole_forward_frac prices all %d iterations "
-                        "against a single pass over the inputs" % n_iter}
+                "whole_forward_frac": round(fwd_frac, 4)}
     if source:
-        roof["traffic_source"] = source
+        roof["traffic_key"] = source
     res = {
         "metric": "CSPN iterations/sec (Mvox*iters/s), 3x3x3x12", "value": round(world * vox * n_iter * steps / 1e6 / elapsed, 1),
         "unit": "Mvox*iters/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (uniform gates normalised over the 26 channels, uniform feature volume; generated on device)",
+        "dtype": "f32", "data": "@data3d",
         "parity_checked": parity,
-        "config": {"workload": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 volume, batch %d per GPU" % B,
-                   "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none (gates pre-normalised by the caller)",
+        "config": {"workload": "@cfg5", "batch_per_gpu": B,
+                   "B_per_gpu": B, "D": D, "H": H, "W": W, "n_iter": n_iter, "norm_type": "none",
                    "algo": "persistent" if persistent else "stepwise",
                    "parallelism": "batch-sharded x%d, no data-path collective" % world},
         "roofline": roof,
@@ -347,7 +404,7 @@ def measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, st
         dt = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": round(gc.shape[0] * D * 40 * W * n_iter / 1e6 / dt, 2), "unit": "Mvox*iters/s",
                                "cores": oracle_threads(), "kind": "port",
-                               "sample": "%d volumes 32x40x608 x %d iters, oracle/cspn_oracle.c (OpenMP)" % (gc.shape[0], n_iter)}
+                               "what": "@cpu_port", "sample": "%d slabs 32x40x608" % gc.shape[0]}
     return res
 
 
@@ -371,7 +428,7 @@ def pmc_traffic(key):
     try:
         t = json.load(open(pmc)).get(key)
         if t:
-            return t["hbm_bytes_per_launch"], t.get("source")
+            return t["hbm_bytes_per_launch"], key
     except Exception:   # noqa: BLE001
         pass
     return None, None
@@ -383,15 +440,12 @@ def roofline2d(m):
     traffic, source = pmc_traffic("%s_B%d_%s%s" % (m["workload"], m["B"], algo_name, "_" + m["layout"] if m.get("layout") not in (None, "planar") else ""))
     r = {
         "bound": "hbm",
-        "kernel": "cspn2d_tsw_kernel (gfx950 assembly main loop; ONE launch per forward: every workgroup builds the row "
-                  "stream of its piece of the linear plan in LDS, nothing else runs inside the timed region)"
+        "kernel": ("@k_tsw4" if ring2d(m["B"], m["H"], W, m["sparse"]) == 12 else "@k_tsw")
                   if algo_name == "fused" and W >= 256 and W % 4 == 0 and n_iter == 24
-                  else "cspn2d_tsw_kernel (gfx950 assembly main loop; a short first pass of %d iterations%s)" % (n_iter % 24, " + %d passes of 24" % (n_iter // 24) if n_iter >= 24 else "")
-                  if algo_name == "fused" and W >= 256 and W % 4 == 0
-                  else "normalize2d_pitch_kernel / pad_rows_kernel -> the fused path on rows padded to a multiple of 4 columns -> unpad_rows_kernel (whole forward)"
-                  if algo_name == "fused_padded"
-                  else "cspn2d_fused_kernel (one launch per forward)" if algo_name.startswith("fused")
-                  else "fold2d_kernel + %d x step2d_kernel (whole forward)" % n_iter,
+                  else "@k_tsw_short" if algo_name == "fused" and W >= 256 and W % 4 == 0
+                  else "@k_padded" if algo_name == "fused_padded"
+                  else "@k_fused_cxx" if algo_name.startswith("fused")
+                  else "@k_stepwise",
         "achieved": round(m["achieved"], 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -402,8 +456,51 @@ def roofline2d(m):
         "device_ms_min": round(m["dev_ms_min"], 4),
     }
     if source:
-        r["traffic_source"] = source
+        r["traffic_key"] = source
     return r
+
+
+LINE_LIMIT = 7500   # the driver keeps an 8 KB tail of stdout
+
+
+def emit_line(res):
+    """the ONE JSON line: compact separators, "@code" strings resolved by profiles/bench_legend.json, and -- should a future leg push it over
+    the limit -- optional detail dropped key by key (recorded under "dropped") rather than a line the driver would cut"""
+    res = dict(res)
+    res["legend"] = "profiles/bench_legend.json"
+    dump = lambda r: json.dumps(r, separators=(",", ":"))
+    line = dump(res)
+    dropped = []
+    optional = [("cpu_baseline", "port_on_64_threads"), ("cpu_baseline", "reference_op_sequence", "by_threads"), ("notes",), ("prewarm_launches",),
+                ("configs", "*", "parity_checked", "images"), ("configs", "*", "roofline", "device_ms_min"), ("configs", "*", "roofline", "peak"),
+                ("configs", "*", "roofline", "unit"), ("configs", "*", "warmup"), ("configs", "*", "steps")]
+    for path in optional:
+        if len(line) <= LINE_LIMIT:
+            break
+        def drop(o, p):
+            if not isinstance(o, dict):
+                return
+            if len(p) == 1:
+                o.pop(p[0], None)
+            elif p[0] == "*":
+                for v in o.values():
+                    drop(v, p[1:])
+            else:
+                drop(o.get(p[0]), p[1:])
+        drop(res, path)
+        dropped.append("/".join(path))
+        res["dropped"] = dropped
+        line = dump(res)
+    return line
+
+
+def ring2d(B, H, W, sparse):
+    """which ring the dispatcher runs a full first pass of this shape on: 12 (cspn2d_tsw4.hip) or 8 (cspn2d_tsw.hip); 0: unknown (no hook library)"""
+    try:
+        from cspn_amd import _lib
+        return int(_lib.load_hooks().cspn_debug_fused2d_ring(B, H, W, 1 if sparse else 0))
+    except Exception:   # noqa: BLE001
+        return 0
 
 
 def timed_leg(step, stream, steps, warmup, prewarm_s):
@@ -459,17 +556,15 @@ def leg_backward2d(lib, _lib, dev, g, h, s, n_iter, norm_name, steps, warmup, pr
     alg = B * H * W * (80 if s is not None else 76)
     traffic, source = pmc_traffic("backward2d_kitti_B%d" % B)
     return {
-        "workload": "cspn2d_backward_f32 (gradient of BASELINE config 3's forward w.r.t. guidance and blur_depth), KITTI %dx%d x %d, %d iters"
-                    % (H, W, B, n_iter),
+        "workload": "@bwd", "shape": [B, H, W], "n_iter": n_iter,
         "value": round(B * H * W * n_iter * steps / 1e6 / elapsed, 1), "unit": "Mpix*iters/s", "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "parity_checked": {"ok": bool(eg <= 2e-4 and eh <= 2e-4), "images": [0], "max_err_over_max_grad": {"guidance": eg, "blur": eh},
-                           "tol": 2e-4, "against": "oracle/backward.py (pinned to the reference's autograd gradients, tests/golden/cspn2d_grad_golden.npz)"},
-        "roofline": {"bound": "hbm", "kernel": "one cspn2d_backward_f32 call: cspn2d_tsw_kernel history sweep + adjoint sweep + bwd_final_ck_kernel",
+                           "tol": 2e-4, "against": "@oracle_bwd"},
+        "roofline": {"bound": "hbm", "kernel": "@k_bwd",
                      "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
-                     "algorithmic_bytes_per_launch": alg, "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4),
-                     "note": "per call, not per kernel: three kernels run back to back inside the event pair"},
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": source,
+                     "algorithmic_bytes_per_launch": alg, "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4)},
     }
 
 
@@ -485,7 +580,7 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
         try:
             m = measure2d(a, lib, _lib, dev, None, 1, 0, False, "weak", steps, warmup, pre, notes, parity=not a.no_parity_check,
                           workload=workload, batch=batch)
-            out[key] = {"workload": "%s, batch %d on one GPU" % (m["desc"], m["B"]), "value": round(m["value"], 1), "unit": "Mpix*iters/s",
+            out[key] = {"workload": m["desc"], "batch": m["B"], "value": round(m["value"], 1), "unit": "Mpix*iters/s",
                         "steps": steps, "warmup": warmup, "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
                         "parity_checked": m["parity"], "roofline": roofline2d(m)}
         except Exception as ex:   # noqa: BLE001 -- a failing leg is reported, it must not cost the headline
@@ -507,10 +602,9 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
         m = measure2d(a, lib, _lib, dev, None, 1, 0, False, "weak", steps, warmup, pre, notes, parity=not a.no_parity_check,
                       workload="kitti", batch=headline["B"], layout="prenorm")
         r = roofline2d(m)
-        r["kernel"] = "cspn2d_tsw_kernel<3,0,0,0> (the same ring, cooking reduced to sigma = sum w, c' = (1 - sigma) H0)"
+        r["kernel"] = "@k_prenorm"
         out["prenorm_kitti_B%d" % m["B"]] = {
-            "workload": "%s, batch %d, guidance pre-normalised by the producer (CSPN_NORM_PRENORM: the reference's gate_wb, cspn.py:85-144; "
-                        "same 40 B/pixel)" % (m["desc"], m["B"]),
+            "workload": m["desc"], "batch": m["B"], "norm": "prenorm",
             "value": round(m["value"], 1), "unit": "Mpix*iters/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(m["elapsed"] / steps * 1e3, 4), "parity_checked": m["parity"], "roofline": r,
             "producer_epilogue_standalone_ms": round(m["normalize_ms"], 4),
@@ -525,7 +619,7 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
     # with the reference's op sequence on the host cores beside it
     fwd2d("config1_plumbing_B1", "plumbing", 1)
     if "error" not in out["config1_plumbing_B1"] and not a.no_cpu_baseline:
-        out["config1_plumbing_B1"]["cpu_reference_op_sequence"] = reference_op_sequence_cpu(228, 304, 12, False, 10.0, a.norm_type, os.cpu_count() or 1, budget_s=8.0)
+        out["config1_plumbing_B1"]["cpu_reference_op_sequence"] = reference_op_sequence_cpu(228, 304, 12, False, 10.0, a.norm_type, physical_cores(), budget_s=8.0)
     try:
         out["config5_vol3d_B4"] = measure_vol3d(a, lib, _lib, dev, None, 1, 0, False, 4, 2, min(steps, 60), min(warmup, 20), pre)
     except Exception as ex:   # noqa: BLE001
@@ -678,6 +772,11 @@ def measure2d(a, lib, _lib, dev, dist, world, rank, shared_gpu, scaling, steps, 
 
 def main():
     a = parse()
+    if a.write_legend:
+        with open(os.path.join(ROOT, "profiles", "bench_legend.json"), "w") as f:
+            json.dump(LEGEND, f, indent=1, sort_keys=True)
+            f.write("\n")
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -763,12 +862,11 @@ def main():
             "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (randn affinity, uniform depth*%g; image i of the global batch from torch.Generator().manual_seed(1000+i) "
-                    "on the CPU, copied to HBM before the timed region)" % scale,
+            "data": "@data2d",
             "prewarm_s": round(m["prewarm_s"], 3), "prewarm_launches": m["prewarm_launches"],
             "parity_checked": m["parity"],
             "config": {
-                "workload": ("%s, batch %d per GPU" % (desc, B)) if a.scaling == "weak"
+                "workload": ("%s, batch %d per GPU" % ("BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216" if desc == "@cfg3" else desc, B)) if a.scaling == "weak"
                             else "%s, global batch %d sharded over %d GPU(s) (%d images on rank 0)" % (desc, total_images, world, B),
                 "B_per_gpu": B, "global_batch": total_images, "H": H, "W": W, "n_iter": n_iter, "norm_type": a.norm_type, "sparse": sparse,
                 "algo": algo_name, "guidance_layout": a.layout, **({"plan_mode": a.plan_mode} if a.plan_mode else {}),
@@ -786,7 +884,7 @@ def main():
                 res["broadcast_error"] = broadcast_error
         if strong is not None:
             res["strong"] = {
-                "workload": "%s, global batch %d sharded over %d GPU(s) (%d images on rank 0)" % (desc, strong["total_images"], world, strong["B"]),
+                "workload": desc, "sharded_over": world,
                 "value": round(strong["value"], 1), "unit": "Mpix*iters/s", "ms_per_step": round(strong["elapsed"] / a.steps * 1e3, 4),
                 "B_per_gpu": strong["B"], "global_batch": strong["total_images"],
                 "roofline_frac_per_gpu": round(strong["achieved"] / HBM_PEAK_GBS, 4), "device_ms_per_launch": round(strong["dev_ms_avg"], 4),
@@ -799,7 +897,7 @@ def main():
             res["notes"] = notes
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W, n_iter, sparse, scale, a.norm_type)
-        print(json.dumps(res), flush=True)
+        print(emit_line(res), flush=True)
     if dist is not None:
         _barrier(dist, notes)
         try:

@@ -67,6 +67,12 @@ int cspn_debug_forward2d_plan(const float* guidance, const float* blur, const fl
     return fused2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream, true, plan_mode);
 }
 
+// which ring a full first pass (24 iterations) of this shape runs on: 12 (round 6, cspn2d_tsw4.hip) or 8 (cspn2d_tsw.hip); 0: not the assembly path
+int cspn_debug_fused2d_ring(int B, int H, int W, int sparse) {
+    if (!tsw2d_supported(B, H, W)) return 0;
+    return tsw4_preferred(B, H, W, sparse != 0) ? 12 : 8;
+}
+
 // the plan of a persistent 3D launch: info[9] = tz, ty, cx, tiles, workgroups launched, bz, by, bx (block of the XCD-aware placement; 0: off), chunks
 int cspn_debug_3d_geo(int B, int D, int H, int W, int n_iter, int* info) {
     persistent3d_geo(B, D, H, W, n_iter, info);
