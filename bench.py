@@ -120,7 +120,7 @@ def parse():
                          "inter-kernel gap (wall time per step), not kernel time; the reported device time is the mean over the bracketed launches")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="N > 1, weak scaling: do not also time BASELINE config 3 as written (--global-batch images sharded over the ranks)")
-    ap.add_argument("--plan-mode", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--plan-mode", type=int, default=0, choices=[0, 1, 2, 3, 8, 9, 10, 16, 17, 18],
                     help="A/B measurements only (through the hook library, not the ABI): 1 = the linear plan without XCD-aware placement, "
                          "2 = the band-group plan of rounds 1-3, 3 = the round-3 loop (experiment builds); 0 = the product (the ABI call)")
     ap.add_argument("--layout", default="planar", choices=["planar", "prenorm", "sited8"],
