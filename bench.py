@@ -411,7 +411,9 @@ def measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, st
 def run_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu):
     """--workload vol3d: BASELINE config 5 as the line's workload"""
     B = 4 if a.batch_per_gpu == 64 else a.batch_per_gpu
-    algo3 = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 2}[a.algo]
+    algo3 = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 2}.get(a.algo)
+    if algo3 is None:
+        raise SystemExit("--workload vol3d takes --algo auto | stepwise | fused (not %s: that is a 2D path)" % a.algo)
     res = measure_vol3d(a, lib, _lib, dev, dist, world, rank, shared_gpu, B, algo3, min(a.steps, 60), min(a.warmup, 20), a.prewarm_s,
                         cpu_base=(world == 1 and not a.no_cpu_baseline))
     if rank == 0:

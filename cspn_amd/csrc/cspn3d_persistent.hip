@@ -53,6 +53,9 @@ constexpr int LTILE = LZ * LYP * LX;             // floats per level buffer
 constexpr unsigned SPIN_MAX = 1u << 18;
 constexpr unsigned CAPTURED_SEQ = 0xffffffffu;   // what a launch captured into a graph stores in the status word (see persistent3d_launch)
 constexpr int MAX_WG = 256 * WG_PER_CU;
+// layout of the sync words behind the exchange buffers: [0, MAX_WG + 64 * 9) flags of the first version, the error word, [1024, 1024 + MAX_WG) the XCC table,
+// [2048, ..) the trace stamps -- an A/B build with more workgroups per CU must not let them overlap
+static_assert(MAX_WG + 64 * 9 + 1 <= 1024 && 1024 + MAX_WG <= 2048, "sync-word layout: error word / XCC table / trace stamps overlap");
 
 struct Geo3 {
     int B, D, H, W, n_iter, halo;
@@ -65,6 +68,7 @@ struct Geo3 {
     int bz, by, bx;          // XCD-aware placement (round 5): the tile grid is cut into <= 8 blocks of bz x by x bx tiles, block k is
     int nby, nbx;            // given to the workgroups with id % 8 == k (ids 8 apart share an XCD: observed, never relied on); bz = 0: off
     int lv0, lvs;            // level output: step it (< n_iter) goes to volume lv0 + it * lvs of `levels`
+    int wt;                  // != 0: every published row goes write-through (no L2-resident stores even where all readers share the XCD): A/B and tests
     int mute;                // MUTE instantiation (test-hook library) only: the workgroup that never publishes
     int C;                   // MULTI instantiation only: value channels that share the gates (feat / out are [B][C][V])
     unsigned seq;            // number of this launch on its device (> 0): what a workgroup that gives up writes to *status
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int dz = (rz == 0 ? -1 : 0); dz <= (rz == TZ - 1 ? 1 : 0); ++dz)
             for (int dy = (ry == 0 ? -1 : 0); dy <= (ry == TY - 1 ? 1 : 0); ++dy)
                 if (dz || dy) rl = rl && same_xcd(dz, dy, 0);
-        if (rl) atomicOr(&s_rowl2, 1ull << tid);
+        if (rl && !g.wt) atomicOr(&s_rowl2, 1ull << tid);
         if (tid < 2 * TZ) {
             // the 128-byte line of x-face quads of plane lz = tid % TZ, side = tid / TZ: read by the tiles at dx = -1 (side 0)
             // / +1 (side 1), dy in {-1, 0, 1} (the line holds all eight rows of the plane), dz as above
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(NTP) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bool xl = true;
             for (int dz = (pz == 0 ? -1 : 0); dz <= (pz == TZ - 1 ? 1 : 0); ++dz)
                 for (int dy = -1; dy <= 1; ++dy) xl = xl && same_xcd(dz, dy, dx);
-            if (xl) atomicOr(&s_xl2, 1u << tid);
+            if (xl && !g.wt) atomicOr(&s_xl2, 1u << tid);
         }
     }
     __syncthreads();   // s_rowl2 / s_xl2 are complete (and s_bail initialised) before anybody publishes
@@ -891,6 +895,7 @@ static int persistent3d_launch(const float* gate, const float* feat, const float
                                bool adjoint, int B, int D, int H, int W, int n_iter, void* ws, hipStream_t st, const P3Options& opt, int C = 1) {
     Geo3 g = make_geo3(B, D, H, W, n_iter, opt.placement);
     g.C = C;
+    g.wt = opt.write_through ? 1 : 0;
     g.lv0 = lv0;
     g.lvs = lvs;
     const size_t total = (size_t)B * D * H * W;

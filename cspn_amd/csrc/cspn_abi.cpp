@@ -87,9 +87,13 @@ int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const floa
     if (algo == CSPN_ALGO_AUTO) {
         algo = cspn2d_auto_algo(B, H, W, n_iter);
         if (algo == CSPN_ALGO_FUSED && ((uintptr_t)out & 15u) != 0) algo = CSPN_ALGO_STEPWISE;   // (the fused kernels store aligned float4)
+        // the padded path runs the fused kernels on planes inside the caller's workspace: those need the same alignment
+        if (algo == CSPN_ALGO_FUSED_PADDED && ((uintptr_t)ws & 15u) != 0) algo = CSPN_ALGO_STEPWISE;
     }
+    if (algo == CSPN_ALGO_FUSED_PADDED && n_iter == 0) algo = CSPN_ALGO_STEPWISE;   // n_iter == 0 is the identity copy below whatever the algo (reference cspn.py:61,66,83)
     if (algo == CSPN_ALGO_FUSED_PADDED) {
-        if (!padded2d_supported(B, H, W, n_iter)) { set_error("FUSED_PADDED is for W %% 4 != 0 (B=%d H=%d W=%d n_iter=%d)", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
+        if (!padded2d_supported(B, H, W, n_iter)) { set_error("FUSED_PADDED needs W %% 4 != 0 and a shape the fused kernels take (B=%d H=%d W=%d n_iter=%d)", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
+        if (((uintptr_t)ws & 15u) != 0) { set_error("FUSED_PADDED needs a 16-byte aligned workspace (its padded planes live there)"); return CSPN_E_UNSUPPORTED; }
         if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, padded2d_workspace(B, H, W, n_iter), CSPN_NORM_PRENORM)) return e;
         return padded2d_forward(guidance, blur, sparse, out, B, H, W, n_iter, norm_type, ws, st);
     }

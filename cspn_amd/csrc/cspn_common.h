@@ -53,7 +53,8 @@ int persistent3d_forward_folded(const float* wf, const float* feat, float* out, 
                                 hipStream_t st);
 // launch options only the test-hook library sets (csrc/cspn_test_hooks.hip): mute = the workgroup that never publishes its
 // boundary (its neighbours then run into the poll timeout), coop = hipLaunchCooperativeKernel instead of the event chain
-struct P3Options { int mute = -1; bool coop = false; bool placement = true; /* false: tiles in plain workgroup order (A/B of the XCD-aware placement) */ };
+struct P3Options { int mute = -1; bool coop = false; bool placement = true; /* false: tiles in plain workgroup order (A/B of the XCD-aware placement) */
+                   bool write_through = false; /* true: no L2-resident stores, every published row goes write-through (A/B, tests) */ };
 // the same run for the backward: adjoint = transposed operator; levels + (lv0 + it * lvs) volumes receive step it < n_iter
 // C > 1: feat / out / the level volumes hold C value channels per volume ([B][C][V]) on shared gates (the MULTI instantiations)
 int persistent3d_run(const float* gate, const float* feat, float* out, float* levels, int lv0, int lvs, bool adjoint, int B, int D,

@@ -83,7 +83,7 @@ int cspn_debug_3d_geo(int B, int D, int H, int W, int n_iter, int* info) {
 int cspn_debug_3d_persistent_error(const void* ws, int B, int D, int H, int W) { return persistent3d_error_word(ws, B, D, H, W); }
 
 // the Paddle-contract persistent launch with tile `mute` never publishing its boundary (-1: nobody); coop bit 0: cooperative launch,
-// bit 1: tiles in plain workgroup order instead of the XCD-aware placement (A/B)
+// bit 1: tiles in plain workgroup order instead of the XCD-aware placement (A/B); bit 2: every published row write-through (no L2-resident stores)
 int cspn_debug_3d_persistent_forward(const float* gate, const float* feat, float* out, int B, int D, int H, int W, int n_iter, int mute,
                                      int coop, void* ws, void* stream) {
     if (!persistent3d_supported(B, D, H, W, n_iter)) return CSPN_E_UNSUPPORTED;
@@ -91,6 +91,7 @@ int cspn_debug_3d_persistent_forward(const float* gate, const float* feat, float
     opt.mute = mute;
     opt.coop = (coop & 1) != 0;
     opt.placement = (coop & 2) == 0;
+    opt.write_through = (coop & 4) != 0;
     return persistent3d_run(gate, feat, out, nullptr, 0, 0, false, B, D, H, W, n_iter, ws, (hipStream_t)stream, opt);
 }
 

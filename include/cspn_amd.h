@@ -90,7 +90,8 @@ int cspn2d_forward_f32(const float* guidance, const float* blur, const float* sp
 int cspn2d_forward_f32_algo(const float* guidance, const float* blur, const float* sparse, float* out,
                             int B, int H, int W, int n_iter, int norm_type, int algo,
                             void* workspace, size_t workspace_bytes, cspn_stream_t stream);
-/* which kernel AUTO would run for this shape: CSPN_ALGO_STEPWISE or CSPN_ALGO_FUSED */
+/* which kernel AUTO would run for this shape: CSPN_ALGO_FUSED, CSPN_ALGO_FUSED_PADDED (W % 4 != 0: rows padded in the workspace) or
+ * CSPN_ALGO_STEPWISE (also AUTO's fallback when `out` / the workspace is not 16-byte aligned) */
 int cspn2d_auto_algo(int B, int H, int W, int n_iter);
 
 /* ---- 2D with the normalisation moved to the producer (second alternative: "fuse normalisation into that conv's
@@ -114,7 +115,10 @@ int cspn2d_forward_prenorm_f32(const float* wb, const float* blur, const float* 
  *   grad_guidance [B,8,H,W]  dL/d(guidance), or NULL to skip
  *   grad_blur     [B,1,H,W]  dL/d(blur_depth) (as level-0 value and as H_0 of the centre / mask terms), or NULL to skip
  * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1.  Fast path (two sweeps of the assembly ring that keep every fourth
- * level + one recomputing final pass): W >= 256, W % 4 == 0, n_iter = 4, 8 .. 24 (24 only until round 5); everything else runs one launch per step. */
+ * level + one recomputing final pass): W >= 256, W % 4 == 0, n_iter = 4, 8 .. 24 (24 only until round 5); everything else runs one launch per step.
+ * For n_iter < 24 both sweeps still run the full 24-level ring and discard the levels beyond n_iter (the checkpoint of level n_iter is stored when the row passes it;
+ * `out` briefly holds level 24 before the level-n_iter plane overwrites it): correct, but their cost does not shrink with n_iter (profiles/r05_backward_niter.jsonl),
+ * and the discarded levels may hold Inf / NaN -- never read `scratch` or `out` of a call that has not completed. */
 size_t cspn2d_backward_workspace_bytes(int B, int H, int W, int n_iter);
 int cspn2d_backward_f32(const float* guidance, const float* blur, const float* sparse, const float* grad_out,
                         float* grad_guidance, float* grad_blur, int B, int H, int W, int n_iter, int norm_type,

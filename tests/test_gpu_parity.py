@@ -432,6 +432,14 @@ def test_3d_xcd_aware_placement_is_bitwise_the_plain_order(B, D, H, W, N):
     assert rc == 0
     cspn_amd.cspn3d_check_status()
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    # the placement with EVERY published row write-through (hook bit 2): the L2-resident stores rest on a plain store
+    # reaching the XCD's L2 in time for the neighbours' sc1 polls -- the pure write-through configuration must give the same bits
+    c = torch.empty_like(h)
+    rc = hooks.cspn_debug_3d_persistent_forward(g.data_ptr(), h.data_ptr(), c.data_ptr(), B, D, H, W, N, -1, 4, ws.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    cspn_amd.cspn3d_check_status()
+    assert torch.equal(a, c)
     assert torch.equal(a, cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="persistent"))   # and deterministic
     s = cspn_amd.cspn3d_forward(g, h, None, N, "none", algo="stepwise")
     assert float((a - s).abs().max()) <= 1e-5 * float(s.abs().max())
