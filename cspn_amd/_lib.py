@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 NORM_TYPES = {"8sum": 0, "8sum_abs": 1, "none": 2, "prenorm": 3}
 ALGOS = {"auto": 0, "stepwise": 1, "fused": 2, "fused_cxx": 3, "fused_padded": 4}
 ALGOS_3D = {"auto": 0, "stepwise": 1, "persistent": 2}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 HOOKS_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcspn_amd_hooks.so")
 
@@ -87,6 +87,10 @@ def load():
     lib.cspn3d_backward_f32.argtypes = [vp] * 5 + [c_int] * 6 + [vp, c_size_t, vp]
     lib.cspn_unpool_f32.restype = c_int
     lib.cspn_unpool_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
+    lib.cspn_guidance_head_workspace_bytes.restype = c_size_t
+    lib.cspn_guidance_head_workspace_bytes.argtypes = [c_int]
+    lib.cspn_guidance_head_f32.restype = c_int
+    lib.cspn_guidance_head_f32.argtypes = [vp] * 5 + [c_int] * 7 + [vp, c_size_t, vp]
     lib.cspn_unpool_backward_f32.restype = c_int
     lib.cspn_unpool_backward_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
     lib.cspn_sparse_sample_workspace_bytes.restype = c_size_t

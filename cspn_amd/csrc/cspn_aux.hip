@@ -254,6 +254,21 @@ int cspn_unpool_f32(const float* x, float* out, size_t NC, int H, int W, int str
     return check_launch("unpool_kernel");
 }
 
+size_t cspn_guidance_head_workspace_bytes(int C) { return C > 0 ? head_workspace(C) : 0; }
+
+int cspn_guidance_head_f32(const float* x, const float* w_guidance, const float* w_blur, float* guidance_out, float* blur_out, int B, int C, int h, int w,
+                           int H, int W, int norm_type, void* workspace, size_t workspace_bytes, cspn_stream_t stream) {
+    if (!x || !w_guidance || !guidance_out || B < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) { set_error("bad argument"); return CSPN_E_BADARG; }
+    if ((w_blur != nullptr) != (blur_out != nullptr)) { set_error("w_blur and blur_out come together"); return CSPN_E_BADARG; }
+    if (H > 2 * h || W > 2 * w) { set_error("H x W = %d x %d exceeds the unpooled %d x %d", H, W, 2 * h, 2 * w); return CSPN_E_BADARG; }
+    if (norm_type != CSPN_NORM_NONE && norm_type != CSPN_NORM_8SUM && norm_type != CSPN_NORM_8SUM_ABS) { set_error("norm_type must be NONE (raw guidance), 8SUM or 8SUM_ABS (gate_wb)"); return CSPN_E_BADARG; }
+    if (!workspace || workspace_bytes < head_workspace(C) || ((uintptr_t)workspace & 7u) != 0) { set_error("workspace: need %zu bytes, 8-byte aligned", head_workspace(C)); return CSPN_E_BADARG; }
+    if ((long long)B * 8 * H * W >= (1ll << 40) || (long long)C * h * w >= (1ll << 31)) { set_error("tensor too large"); return CSPN_E_UNSUPPORTED; }
+    if (B == 0) return 0;
+    const int mode = norm_type == CSPN_NORM_NONE ? 0 : (norm_type == CSPN_NORM_8SUM ? 1 : 2);
+    return head_forward(x, w_guidance, w_blur, guidance_out, blur_out, B, C, h, w, H, W, mode, workspace, (hipStream_t)stream);
+}
+
 int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, int H, int W, int stride, cspn_stream_t stream) {
     if (!grad_out || !grad_x || H <= 0 || W <= 0 || stride < 1) { set_error("bad argument"); return CSPN_E_BADARG; }
     const size_t n_in = NC * (size_t)H * W;

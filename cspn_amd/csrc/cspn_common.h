@@ -76,6 +76,12 @@ size_t backward3d_workspace(int B, int D, int H, int W, int n_iter, int C = 1);
 int backward3d(const float* g, const float* feat, const float* gout, float* gg, float* gf, int B, int D, int H, int W, int n_iter,
                void* ws, hipStream_t st, bool stepwise_only = false /* test-hook library: one launch per step */, int C = 1);
 
+// ---- the producer of the path's inputs (cspn_head.hip): Unpool + 3x3 conv C -> 8 (guidance) and C -> 1 (blur) as one kernel; mode 0 raw guidance,
+// 1 / 2 gate_wb of '8sum' / '8sum_abs' (the normalisation fused behind the conv) ----
+size_t head_workspace(int C);
+int head_forward(const float* x, const float* w6, const float* w5, float* gout, float* bout, int B, int C, int h, int w, int H, int W, int mode,
+                 void* ws, hipStream_t st);
+
 // ---- fused path (all iterations in one launch; time-skewed wave ring) ----
 bool fused2d_supported(int B, int H, int W, int n_iter);
 size_t fused2d_workspace(int B, int H, int W, int n_iter);

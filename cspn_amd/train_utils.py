@@ -9,6 +9,9 @@
 
     createSparseDepthImage(depth_image, n_sample)                 createSparseDepthImage(depth, n_sample, mode='nyu'|'kitti',
       nyu_dataset_loader.py:135-144, kitti_dataset_loader.py:138-148   seed): the Bernoulli mask drawn on the GPU, batched
+    gud_up_proj_layer6(x), gud_up_proj_layer5(x)                  guidance_heads(x, layer6.conv1.weight, layer5.conv1.weight, oheight, owidth
+      torch_resnet_cspn_nyu.py:187-206, :318-319, :372-373          [, norm_type]): both Simple_Gudi_UpConv_Block_Last_Layer heads (Unpool + 3x3 conv) as
+                                                                  ONE kernel; with norm_type the guidance comes back as gate_wb (forward only)
 
 The reference moves every prediction to the host before reducing it (train.py:204-206, eval.py:146-150)."""
 import torch
@@ -136,3 +139,32 @@ def createSparseDepthImage(depth_image, n_sample, mode="nyu", seed=0):
                                         ws.data_ptr(), wsb, torch.cuda.current_stream(d.device).cuda_stream)
     _lib.check(rc, "cspn_sparse_sample_f32")
     return out
+
+
+def guidance_heads(x, weight_guidance, weight_blur=None, oheight=0, owidth=0, norm_type=None):
+    """The producer of the propagation's inputs: what the reference computes as
+        guidance = self.gud_up_proj_layer6(x); x = self.gud_up_proj_layer5(x)          (torch_resnet_cspn_nyu.py:372-373)
+    with both heads Simple_Gudi_UpConv_Block_Last_Layer (:187-206: Unpool + narrow to (oheight, owidth) + bias-free 3x3 conv), in ONE kernel that never
+    multiplies the structurally zero taps.  x [B,C,h,w]; weight_guidance = layer6.conv1.weight [8,C,3,3]; weight_blur = layer5.conv1.weight [1,C,3,3] or None.
+    norm_type None: -> (guidance [B,8,H,W], blur [B,1,H,W] | None), bit-compatible inputs of Affinity_Propagate(..., norm_type)(guidance, blur, sparse).
+    norm_type '8sum' | '8sum_abs': the guidance comes back normalised -- gate_wb of affinity_normalization (cspn.py:85-144) -- for
+    cspn2d_forward(gate_wb, blur, sparse, n_iter, 'prenorm'): no stand-alone normalisation pass.  Forward only (inference / the frozen-head case)."""
+    lib = _lib.load()
+    xx = _prep(x, "x")
+    B, C, h, w = xx.shape
+    wg = _prep(weight_guidance, "weight_guidance", (8, C, 3, 3))
+    wb = _prep(weight_blur, "weight_blur", (1, C, 3, 3)) if weight_blur is not None else None
+    H, W = (int(oheight), int(owidth)) if (oheight and owidth) else (2 * h, 2 * w)
+    g = torch.empty(B, 8, H, W, dtype=torch.float32, device=xx.device)
+    b = torch.empty(B, 1, H, W, dtype=torch.float32, device=xx.device) if wb is not None else None
+    norm = _lib.NORM_TYPES["none" if norm_type is None else norm_type]
+    if norm_type not in (None, "8sum", "8sum_abs"):
+        raise ValueError("norm_type must be None (raw guidance), '8sum' or '8sum_abs' (gate_wb)")
+    with torch.cuda.device(xx.device):
+        wsb = lib.cspn_guidance_head_workspace_bytes(C)
+        ws = _workspace(wsb, xx.device)
+        rc = lib.cspn_guidance_head_f32(xx.data_ptr(), wg.data_ptr(), wb.data_ptr() if wb is not None else None, g.data_ptr(),
+                                        b.data_ptr() if b is not None else None, B, C, h, w, H, W, norm, ws.data_ptr(), wsb,
+                                        torch.cuda.current_stream(xx.device).cuda_stream)
+    _lib.check(rc, "cspn_guidance_head_f32")
+    return g, b

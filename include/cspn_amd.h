@@ -40,10 +40,11 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 4   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32;
+#define CSPN_ABI_VERSION 5   /* 2: cspn3d_check_status, CSPN_E_ASYNC, smaller cspn3d_workspace_bytes_ex; 3: cspn3d_forward_multi_f32;
                               * 4: CSPN_NORM_PRENORM, cspn2d_normalize_f32, cspn2d_forward_prenorm_f32, cspn3d_backward_multi_f32; the
                               *    sited8 experiment's three entry points left the ABI (hook library, experiment builds); CSPN_ALGO_FUSED_PADDED
-                              *    (what AUTO returns for W % 4 != 0; cspn2d_workspace_bytes grows accordingly for such widths) */
+                              *    (what AUTO returns for W % 4 != 0; cspn2d_workspace_bytes grows accordingly for such widths);
+                              * 5: cspn_guidance_head_f32 (the producer of the path's inputs) */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -228,6 +229,20 @@ int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, in
 size_t cspn_sparse_sample_workspace_bytes(size_t n_images);
 int cspn_sparse_sample_f32(const float* depth, float* sparse_out, size_t n_images, size_t hw, int n_sample, int mode,
                            unsigned long long seed, void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
+/* ---- the producer of the path's inputs (producer half): the two heads Simple_Gudi_UpConv_Block_Last_Layer of the reference backbone
+ * (cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206; gud_up_proj_layer6 64 -> 8 = guidance and gud_up_proj_layer5 64 -> 1 = blur depth, :318-319,
+ * called :372-373) as ONE kernel: Unpool (:41-54, narrowed to H x W :196-201) + 3x3 conv, padding 1, no bias (:190) -- the three quarters of the
+ * unpooled taps that are structurally zero are never multiplied.
+ *   x [B,C,h,w];  w_guidance [8,C,3,3];  w_blur [1,C,3,3] or NULL;  guidance_out [B,8,H,W];  blur_out [B,1,H,W] or NULL;  H <= 2h, W <= 2w (the reference: exactly 2x).
+ *   norm_type CSPN_NORM_NONE: guidance_out = the raw guidance, what gud_up_proj_layer6 returns (feed it to cspn2d_forward_f32 with '8sum' / '8sum_abs');
+ *   CSPN_NORM_8SUM / CSPN_NORM_8SUM_ABS: guidance_out = gate_wb = affinity_normalization (cspn.py:85-144) of that guidance, fused behind the conv (IEEE
+ *   division: 0 / 0 = NaN as in the reference) -- the input contract of cspn2d_forward_f32 with CSPN_NORM_PRENORM; no stand-alone normalisation pass.
+ * workspace: cspn_guidance_head_workspace_bytes(C) (the packed weights).  Forward only. */
+size_t cspn_guidance_head_workspace_bytes(int C);
+int cspn_guidance_head_f32(const float* x, const float* w_guidance, const float* w_blur, float* guidance_out, float* blur_out,
+                           int B, int C, int h, int w, int H, int W, int norm_type,
+                           void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 #ifdef __cplusplus
 }

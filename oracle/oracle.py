@@ -95,3 +95,29 @@ def cspn3d_oracle(gate, feat, sparse=None, n_iter=12, norm_type="8sum_abs"):
     if rc:
         raise RuntimeError("cspn3d_oracle_f32 failed: %d" % rc)
     return out
+
+
+def guidance_head_oracle(x, w_guidance, w_blur=None, oheight=0, owidth=0):
+    """Simple_Gudi_UpConv_Block_Last_Layer x 2 of the reference backbone (cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206; the heads
+    gud_up_proj_layer6 / gud_up_proj_layer5 of :318-319, called :372-373), restated in numpy, fp64 accumulation:
+        Unpool (:41-54: conv_transpose2d with a one-hot 2x2 kernel, stride 2: U[c][2i][2j] = x[c][i][j], zeros elsewhere)
+        -> narrow to (oheight, owidth) if both != 0 (:196-201)  -> 3x3 conv, padding 1, no bias (:190, :203-206).
+    x [B,C,h,w], w_guidance [8,C,3,3], w_blur [1,C,3,3] or None -> (guidance [B,8,H,W], blur [B,1,H,W] or None), float32."""
+    x = _f32(x)
+    B, C, h, w = x.shape
+    U = np.zeros((B, C, 2 * h, 2 * w), np.float64)
+    U[:, :, 0::2, 0::2] = x
+    if oheight and owidth:
+        U = U[:, :, :oheight, :owidth]
+    H, W = U.shape[2], U.shape[3]
+    Up = np.zeros((B, C, H + 2, W + 2), np.float64)
+    Up[:, :, 1:-1, 1:-1] = U
+
+    def conv(wt):
+        wt = np.asarray(wt, np.float64)
+        out = np.zeros((B, wt.shape[0], H, W), np.float64)
+        for ky in range(3):
+            for kx in range(3):
+                out += np.einsum("oc,bcyx->boyx", wt[:, :, ky, kx], Up[:, :, ky:ky + H, kx:kx + W])
+        return out.astype(np.float32)
+    return conv(w_guidance), (conv(w_blur) if w_blur is not None else None)

@@ -67,3 +67,29 @@ def reference_gate_wb(guidance, norm_type="8sum"):
         m(guidance, torch.zeros(B, 1, H, W), None)           # creates m.sum_conv exactly as the reference does
         wb, gs = m.affinity_normalization(guidance)
     return wb[:, :, 0, 1:-1, 1:-1].contiguous(), gs.contiguous()
+
+
+REF_MODEL = "/root/reference/cspn_pytorch/models/torch_resnet_cspn_nyu.py"
+
+
+def reference_guidance_heads(x, w_guidance, w_blur, oheight=0, owidth=0):
+    """-> (guidance [B,8,H,W], blur [B,1,H,W]) computed by the UNMODIFIED reference classes Simple_Gudi_UpConv_Block_Last_Layer
+    (/root/reference/cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206; Unpool :41-54), instantiated as the backbone does (:318-319)
+    with the given conv weights.  The file does `import cspn as post_process` (:12): its directory goes on sys.path for the import."""
+    import sys
+    d = os.path.dirname(REF_MODEL)
+    sys.path.insert(0, d)
+    try:
+        with cuda_is_identity():
+            spec = importlib.util.spec_from_file_location("_reference_resnet_cspn", REF_MODEL)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            C = x.shape[1]
+            l6 = mod.Simple_Gudi_UpConv_Block_Last_Layer(C, 8, oheight, owidth)
+            l5 = mod.Simple_Gudi_UpConv_Block_Last_Layer(C, 1, oheight, owidth)
+            with torch.no_grad():
+                l6.conv1.weight.copy_(w_guidance)
+                l5.conv1.weight.copy_(w_blur)
+                return l6(x), l5(x)
+    finally:
+        sys.path.remove(d)

@@ -53,7 +53,7 @@ def _run(g, h, s, N, norm, algo):
 
 def test_library_is_loaded_and_gpu_present():
     assert torch.cuda.is_available()
-    assert cspn_amd.load().cspn_abi_version() == 4
+    assert cspn_amd.load().cspn_abi_version() == 5
 
 
 def test_golden_vectors(golden):

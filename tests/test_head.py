@@ -1,0 +1,135 @@
+"""The producer of the propagation's inputs (producer half): cspn_guidance_head_f32 = both reference heads Simple_Gudi_UpConv_Block_Last_Layer
+(cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206: Unpool :41-54 + bias-free 3x3 conv; gud_up_proj_layer6 / gud_up_proj_layer5 of :318-319, called :372-373) as
+one kernel, optionally with affinity_normalization (cspn.py:85-144) fused behind it (gate_wb).  Golden vectors: tests/golden/head_golden.npz, produced by the
+UNMODIFIED reference classes (tests/golden/make_head_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import guidance_head_oracle, cspn2d_gate_wb_oracle, cspn2d_oracle  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
+NAMES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def _case(name):
+    g = {k.split("/")[1]: GOLD[k] for k in GOLD.files if k.startswith(name + "/")}
+    return g, int(g["meta"][0]), int(g["meta"][1])
+
+
+def _rel(a, b):
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    return float(np.abs(a[fin] - b[fin]).max() / max(1e-30, np.abs(b[fin]).max())) if fin.any() else 0.0
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_head_oracle_vs_reference_golden(name):
+    """the numpy restatement (oracle/oracle.py guidance_head_oracle) is pinned to what the unmodified reference layers returned"""
+    g, oh, ow = _case(name)
+    guid, blur = guidance_head_oracle(g["x"], g["w6"], g["w5"], oh, ow)
+    assert guid.shape == g["guidance"].shape and blur.shape == g["blur"].shape
+    assert _rel(guid, g["guidance"]) <= 2e-6 and _rel(blur, g["blur"]) <= 2e-6
+    # and the normalisation behind it: the oracle's gate_wb of the oracle's guidance against the reference's gate_wb of the reference's guidance
+    for norm in ("8sum", "8sum_abs"):
+        wb = cspn2d_gate_wb_oracle(g["guidance"], norm)
+        assert _rel(wb, g["gate_wb_" + norm]) <= 2e-6
+
+
+def test_head_oracle_vs_live_reference():
+    from oracle import ref_harness
+    if not ref_harness.available():
+        pytest.skip("/root/reference not present (GPU box)")
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 6, 5, generator=gen)
+    w6, w5 = torch.randn(8, 64, 3, 3, generator=gen) * 0.05, torch.randn(1, 64, 3, 3, generator=gen) * 0.05
+    rg, rb = ref_harness.reference_guidance_heads(x, w6, w5, 12, 10)
+    og, ob = guidance_head_oracle(x.numpy(), w6.numpy(), w5.numpy(), 12, 10)
+    assert _rel(og, rg.numpy()) <= 2e-6 and _rel(ob, rb.numpy()) <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_head_kernel_vs_reference_golden(name):
+    import cspn_amd
+    from cspn_amd.train_utils import guidance_heads
+    g, oh, ow = _case(name)
+    x, w6, w5 = _dev(g["x"]), _dev(g["w6"]), _dev(g["w5"])
+    guid, blur = guidance_heads(x, w6, w5, oh, ow)
+    torch.cuda.synchronize()
+    assert _rel(guid.cpu().numpy(), g["guidance"]) <= 1e-5 and _rel(blur.cpu().numpy(), g["blur"]) <= 1e-5
+    g2, none = guidance_heads(x, w6, None, oh, ow)                      # guidance only
+    assert none is None and torch.equal(g2, guid)
+    for norm in ("8sum", "8sum_abs"):
+        wb, blur2 = guidance_heads(x, w6, w5, oh, ow, norm_type=norm)
+        torch.cuda.synchronize()
+        assert torch.equal(blur2, blur)
+        ref = g["gate_wb_" + norm]
+        got = wb.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), name      # 0 / 0 = NaN exactly where the reference has it (cspn.py:138)
+        # (a raw guidance value at 1e-7 of the others carries 1e-5 x its own size of summation-order noise: absolute floor at the weights' scale)
+        fin = np.isfinite(ref)
+        assert np.abs(got[fin] - ref[fin]).max() <= 2e-5, (name, norm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,w,oh,ow", [(2, 114, 152, 228, 304), (1, 152, 608, 304, 1216), (3, 40, 125, 79, 249)])
+def test_head_kernel_vs_torch_conv_and_through_the_forward(B, h, w, oh, ow):
+    """the reference's own sizes (NYU 114x152 -> 228x304, :318-319) and KITTI: against torch's conv_transpose2d + conv2d on the GPU (the reference's op
+    sequence), and END TO END: head (gate_wb) -> forward with 'prenorm' == head (raw) -> forward with '8sum' == oracle on the raw guidance"""
+    import cspn_amd
+    import torch.nn.functional as F
+    from cspn_amd.train_utils import guidance_heads
+    gen = torch.Generator(device="cuda").manual_seed(B + h + w)
+    C = 64
+    x = torch.randn(B, C, h, w, generator=gen, device="cuda")
+    w6 = torch.randn(8, C, 3, 3, generator=gen, device="cuda") / (3.0 * C ** 0.5)
+    w5 = torch.randn(1, C, 3, 3, generator=gen, device="cuda") / (3.0 * C ** 0.5) + 0.02
+    up = torch.zeros(C, 1, 2, 2, device="cuda")
+    up[:, :, 0, 0] = 1
+    U = F.conv_transpose2d(x, up, stride=2, groups=C)[:, :, :oh, :ow]
+    rg = F.conv2d(U.double(), w6.double(), padding=1).float()
+    rb = F.conv2d(U.double(), w5.double(), padding=1).float()
+    guid, blur = guidance_heads(x, w6, w5, oh, ow)
+    assert float((guid - rg).abs().max() / rg.abs().max()) <= 1e-5
+    assert float((blur - rb).abs().max() / rb.abs().max()) <= 1e-5
+    wb, blur2 = guidance_heads(x, w6, w5, oh, ow, norm_type="8sum")
+    assert torch.equal(blur2, blur)
+    ref_wb = cspn_amd.cspn2d_normalize(guid, "8sum")                      # the stand-alone normalisation of the engine (pinned to the reference's gate_wb)
+    assert torch.equal(torch.isnan(wb), torch.isnan(ref_wb))
+    assert float((wb - ref_wb).abs().nan_to_num().max()) <= 1e-5
+    if ow % 4 == 0 and ow >= 256:
+        depth = blur.abs() * 10 + 1.0
+        a = cspn_amd.cspn2d_forward(wb, depth, None, 24, "prenorm")
+        b_ = cspn_amd.cspn2d_forward(guid, depth, None, 24, "8sum")
+        torch.cuda.synchronize()
+        assert float((a - b_).abs().max() / b_.abs().max()) <= 1e-5
+        ref = cspn2d_oracle(guid[:1].cpu(), depth[:1].cpu(), None, 24, "8sum")
+        assert _rel(a[:1].cpu().numpy(), ref) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_head_argument_checks():
+    import cspn_amd
+    from cspn_amd import _lib
+    lib = cspn_amd.load()
+    x = torch.zeros(1, 4, 3, 3, device="cuda")
+    w6 = torch.zeros(8, 4, 3, 3, device="cuda")
+    out = torch.zeros(1, 8, 6, 6, device="cuda")
+    ws = torch.zeros(lib.cspn_guidance_head_workspace_bytes(4), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.cspn_guidance_head_f32(x.data_ptr(), w6.data_ptr(), None, out.data_ptr(), None, 1, 4, 3, 3, 7, 6, 2, ws.data_ptr(), ws.numel(), st) == -1   # H > 2 h
+    assert lib.cspn_guidance_head_f32(x.data_ptr(), w6.data_ptr(), None, out.data_ptr(), None, 1, 4, 3, 3, 6, 6, _lib.NORM_TYPES["prenorm"], ws.data_ptr(), ws.numel(), st) == -1
+    assert lib.cspn_guidance_head_f32(x.data_ptr(), w6.data_ptr(), w6.data_ptr(), out.data_ptr(), None, 1, 4, 3, 3, 6, 6, 2, ws.data_ptr(), ws.numel(), st) == -1   # w_blur without blur_out
+    assert lib.cspn_guidance_head_f32(x.data_ptr(), w6.data_ptr(), None, out.data_ptr(), None, 1, 4, 3, 3, 6, 6, 2, ws.data_ptr(), 8, st) == -1          # workspace too small
+    assert lib.cspn_guidance_head_f32(x.data_ptr(), w6.data_ptr(), None, out.data_ptr(), None, 1, 4, 3, 3, 6, 6, 2, ws.data_ptr(), ws.numel(), st) == 0
