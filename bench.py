@@ -72,6 +72,13 @@ LEGEND = {
     "cfg3": "BASELINE config 3: 2D CSPN 3x3, 24 iters, KITTI 304x1216 (batch 64 sharded over 8 GPUs as written: 8 per GPU; the headline runs 64 per GPU)",
     "cfg4": "BASELINE config 4: 2D CSPN 3x3 + sparse-depth replacement (500-point mask), 24 iters, KITTI 304x1216, batch 32 on one GPU",
     "cfg5": "BASELINE config 5: 3D CSPN 3x3x3, 12 iters, 32x160x608 cost volume, batch 4 on one GPU; gates pre-normalised by the caller (Paddle contract)",
+    "head": "the producer of BASELINE config 3's inputs (SURVEY 8f-2): both guidance heads of the reference backbone (torch_resnet_cspn_nyu.py:187-206, 372-373: Unpool + "
+            "3x3 conv 64 -> 8 and 64 -> 1) on a [64,64,152,608] feature map; algorithmic work = the 9 non-zero products per input pixel, input channel and output "
+            "plane (2 x 81 x C FLOP per input pixel); head_plus_forward_ms = this head + the headline forward on its outputs, one stream, one event pair; "
+            "torch_heads_ms = the reference's op sequence for the heads (conv_transpose2d + two conv2d, MIOpen) on the same GPU",
+    "k_head": "head_raw_kernel (cspn_head.hip): packed fp32 FMAs (no fp32 MFMA gain on gfx950: v_mfma_f32 and v_pk_fma_f32 share the 157.3 TFLOP/s peak), feature "
+              "rows by LDS-DMA 8 channels ahead, weights as scalar operands",
+    "oracle_head": "oracle/oracle.py guidance_head_oracle (numpy, fp64 accumulation), pinned to the unmodified reference's modules (tests/golden/head_golden.npz)",
     "bwd": "cspn2d_backward_f32: gradient of BASELINE config 3's forward w.r.t. guidance and blur_depth (reference train.py:196-198), 76 B/pixel algorithmic",
 }
 BACKBONE_PARAMS = 256_078_272  # resnet50-CSPN fp32 parameter count (probed)
@@ -570,6 +577,65 @@ def leg_backward2d(lib, _lib, dev, g, h, s, n_iter, norm_name, steps, warmup, pr
     }
 
 
+F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
+
+
+def leg_head(lib, _lib, dev, B, n_iter, norm_name, steps, warmup, prewarm_s):
+    """cspn_guidance_head_f32 (raw guidance + blur) on the feature map behind BASELINE config 3's batch, alone and followed by the forward"""
+    import torch.nn.functional as F
+    import cspn_amd
+    from cspn_amd.train_utils import guidance_heads
+    C, h, w = 64, 152, 608
+    gen = torch.Generator().manual_seed(4242)
+    x = torch.randn(B, C, h, w, generator=gen).to(dev)
+    w6 = (torch.randn(8, C, 3, 3, generator=gen) / (3.0 * C ** 0.5)).to(dev)
+    w5 = (torch.randn(1, C, 3, 3, generator=gen) / (3.0 * C ** 0.5) + 0.02).to(dev)
+    stream = torch.cuda.current_stream(dev)
+    keep = {}
+
+    def step():
+        keep["g"], keep["b"] = guidance_heads(x, w6, w5)
+
+    elapsed, dev_ms = timed_leg(step, stream, steps, warmup, prewarm_s)
+    ms = sum(dev_ms) / len(dev_ms)
+    flop = 2.0 * 81 * C * B * h * w
+    from oracle import guidance_head_oracle
+    rg, rb = guidance_head_oracle(x[:1].cpu().numpy(), w6.cpu().numpy(), w5.cpu().numpy())
+    rg, rb = torch.from_numpy(rg), torch.from_numpy(rb)
+    eg = float((keep["g"][:1].cpu() - rg).abs().max() / rg.abs().max())
+    eb = float((keep["b"][:1].cpu() - rb).abs().max() / rb.abs().max())
+
+    def e2e():
+        g_, b_ = guidance_heads(x, w6, w5)
+        keep["o"] = cspn_amd.cspn2d_forward(g_, b_, None, n_iter, norm_name)
+
+    _, e2e_ms = timed_leg(e2e, stream, steps, min(warmup, 5), 0.0)
+    up = torch.zeros(C, 1, 2, 2, device=dev)
+    up[:, :, 0, 0] = 1
+
+    def torch_heads():
+        U = F.conv_transpose2d(x, up, stride=2, groups=C)
+        keep["tg"], keep["tb"] = F.conv2d(U, w6, padding=1), F.conv2d(U, w5, padding=1)
+
+    res = {
+        "workload": "@head", "shape": [B, C, h, w], "value": round(B * 4 * h * w * steps / 1e6 / elapsed, 1), "unit": "Mpix/s (output pixels)",
+        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "parity_checked": {"ok": bool(eg <= 1e-5 and eb <= 1e-5), "images": [0], "max_err_over_max": {"guidance": eg, "blur": eb}, "tol": 1e-5,
+                           "against": "@oracle_head"},
+        "roofline": {"bound": "mfma", "kernel": "@k_head", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(flop / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flop_per_launch": flop,
+                     "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4)},
+        "head_plus_forward_ms": round(sum(e2e_ms) / len(e2e_ms), 4),
+    }
+    try:
+        _, t_ms = timed_leg(torch_heads, stream, min(steps, 5), 2, 0.0)
+        res["torch_heads_ms"] = round(sum(t_ms) / len(t_ms), 3)
+        res["raw_vs_torch_max_rel"] = float((keep["g"] - keep["tg"]).abs().max() / keep["tg"].abs().max())
+    except Exception as ex:   # noqa: BLE001
+        res["torch_heads_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:120])
+    return res
+
+
 def extra_configs(a, lib, _lib, dev, headline, notes):
     """N = 1: the other BASELINE configs and the training path, each timed like the headline (own prewarm, counted warm-up, K steps
     bracketed by synchronize, per-launch device time from HIP events on the launch stream, parity against the oracle AFTER the
@@ -613,6 +679,11 @@ def extra_configs(a, lib, _lib, dev, headline, notes):
             "vs_headline_device_ms": round(m["dev_ms_avg"] / headline["dev_ms_avg"], 4)}
     except Exception as ex:   # noqa: BLE001
         out["prenorm_kitti_B%d" % headline["B"]] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    torch.cuda.empty_cache()
+    try:
+        out["head_kitti_B%d" % headline["B"]] = leg_head(lib, _lib, dev, headline["B"], headline["n_iter"], a.norm_type, steps, warmup, pre)
+    except Exception as ex:   # noqa: BLE001
+        out["head_kitti_B%d" % headline["B"]] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
     torch.cuda.empty_cache()
     fwd2d("config4_kitti_sparse_B32", "kitti_sparse", 32)
     fwd2d("config2_nyu_B16", "nyu", 16)

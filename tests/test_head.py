@@ -73,7 +73,8 @@ def test_head_kernel_vs_reference_golden(name):
     for norm in ("8sum", "8sum_abs"):
         wb, blur2 = guidance_heads(x, w6, w5, oh, ow, norm_type=norm)
         torch.cuda.synchronize()
-        assert torch.equal(blur2, blur)
+        # (the fused kernel sums a pixel's four odd-odd taps as three partial sums, the raw kernel as one chain: same products, different association)
+        assert _rel(blur2.cpu().numpy(), blur.cpu().numpy()) <= 2e-6
         ref = g["gate_wb_" + norm]
         got = wb.cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref)), name      # 0 / 0 = NaN exactly where the reference has it (cspn.py:138)
@@ -104,7 +105,7 @@ def test_head_kernel_vs_torch_conv_and_through_the_forward(B, h, w, oh, ow):
     assert float((guid - rg).abs().max() / rg.abs().max()) <= 1e-5
     assert float((blur - rb).abs().max() / rb.abs().max()) <= 1e-5
     wb, blur2 = guidance_heads(x, w6, w5, oh, ow, norm_type="8sum")
-    assert torch.equal(blur2, blur)
+    assert float((blur2 - blur).abs().max() / blur.abs().max()) <= 2e-6     # (two kernels, two summation orders)
     ref_wb = cspn_amd.cspn2d_normalize(guid, "8sum")                      # the stand-alone normalisation of the engine (pinned to the reference's gate_wb)
     assert torch.equal(torch.isnan(wb), torch.isnan(ref_wb))
     assert float((wb - ref_wb).abs().nan_to_num().max()) <= 1e-5
