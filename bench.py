@@ -604,6 +604,7 @@ def leg_head(lib, _lib, dev, B, n_iter, norm_name, steps, warmup, prewarm_s):
     rg, rb = torch.from_numpy(rg), torch.from_numpy(rb)
     eg = float((keep["g"][:1].cpu() - rg).abs().max() / rg.abs().max())
     eb = float((keep["b"][:1].cpu() - rb).abs().max() / rb.abs().max())
+    traffic, source = pmc_traffic("head_kitti_B%d" % B)
 
     def e2e():
         g_, b_ = guidance_heads(x, w6, w5)
@@ -623,7 +624,8 @@ def leg_head(lib, _lib, dev, B, n_iter, norm_name, steps, warmup, prewarm_s):
         "parity_checked": {"ok": bool(eg <= 1e-5 and eb <= 1e-5), "images": [0], "max_err_over_max": {"guidance": eg, "blur": eb}, "tol": 1e-5,
                            "against": "@oracle_head"},
         "roofline": {"bound": "mfma", "kernel": "@k_head", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flop / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flop_per_launch": flop,
+                     "frac": round(flop / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_key": source,
+                     "algorithmic_flop_per_launch": flop, "hbm_bytes_unique": 4 * B * (C * h * w + 9 * 4 * h * w),
                      "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4)},
         "head_plus_forward_ms": round(sum(e2e_ms) / len(e2e_ms), 4),
     }
