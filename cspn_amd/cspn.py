@@ -51,6 +51,17 @@ class _CSPN2dFunction(torch.autograd.Function):
         return gg, gh, None, None, None, None, None
 
 
+def propagate_prenorm(gate_wb, blur_depth, sparse_depth=None, n_iter=24, algo="auto", keep_history=True):
+    """The loop of reference cspn.py:66-81 started from the tensor its affinity_normalization returns (gate_wb [B,8,H,W], cropped to the
+    image: what cspn_amd.cspn2d_normalize or the guidance head with norm_type='8sum' emit) -- the pre-normalised input contract
+    (CSPN_NORM_PRENORM), differentiable: the gradients w.r.t. gate_wb and blur_depth are what torch autograd computes through the
+    reference forward for those two tensors (tests/golden/cspn2d_grad_prenorm_golden.npz); chaining dL/dgate_wb into whatever produced it
+    is the caller's autograd."""
+    if n_iter == 0:
+        return blur_depth
+    return _CSPN2dFunction.apply(gate_wb, blur_depth, sparse_depth, int(n_iter), "prenorm", algo, keep_history)
+
+
 class Affinity_Propagate(nn.Module):
 
     def __init__(self, prop_time, prop_kernel, norm_type='8sum'):

@@ -9,6 +9,8 @@
 //           dL/dw_k = (1-m)(dW'_k - dC H_0);   dL/dH_0 = A_0 + dC ((1-m)(1-sigma) + m)
 //           dL/dG_k = dL/dw_k / S - sign(G_k) (sum_j dL/dw_j G_j) / S^2          (torch: d|x|/dx = sign(x), 0 at 0)
 //           dL/dg_k(p + off_k) = dL/dG_k(p)  [* sign(g) for '8sum_abs'];  elements no pixel reads get 0.
+// CSPN_NORM_PRENORM (round 6): `guidance` is the reference's gate_wb (cspn.py:85-144), w_k(p) = wb_k(p) at the pixel itself: the chain ends at
+//           dL/dwb_k = (1-m)(dW'_k - dC H_0),   dL/dH_0 = A_0 + dC ((1-m)(1 - sum_k wb_k) + m).
 // 24-iteration passes on images the ring kernel takes: two sweeps of that kernel (forward keeping H_4, H_8 .. H_20 and the folded
 // coefficients, adjoint keeping A_20 .. A_4) + bwd_final_ck_kernel, which recomputes the levels in between tile by tile.
 // Everything else: fold + one launch per step for both recursions (every level kept) + bwd_final_kernel.
@@ -116,6 +118,17 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float* __restrict_
         }
         return;
     }
+    if (norm == CSPN_NORM_PRENORM) {  // the planes are the reference's gate_wb, read at the pixel itself: w'_k = (1-m) wb_k, c' = ((1-m)(1-sigma) + m) H_0
+        float sigma = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sigma += gbp[k * HW + r];
+        if (gb) gb[idx] = a0 + dC * (om * (1.f - sigma) + m);
+        if (gg) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gg[(size_t)b * 8 * HW + k * HW + r] = om * (dW[k] - dC * h0);
+        }
+        return;
+    }
     float G[8], S = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -197,6 +210,26 @@ __device__ __forceinline__ void bwd_epilogue4(const float* __restrict__ g, const
             for (int k = 0; k < 8; ++k)
                 *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
                     make_float4((1.f - m[0]) * dW[k][0], (1.f - m[1]) * dW[k][1], (1.f - m[2]) * dW[k][2], (1.f - m[3]) * dW[k][3]);
+        }
+        return;
+    }
+    if (norm == CSPN_NORM_PRENORM) {  // gate_wb as given, at the pixel itself (see bwd_final_kernel): no normalisation chain, no scatter
+        float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(gbp + k * HW + (size_t)y * W + x);
+            sg[0] += q.x; sg[1] += q.y; sg[2] += q.z; sg[3] += q.w;
+        }
+        float om[4], ch[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+        if (gb) *reinterpret_cast<float4*>(gb + idx) = make_float4(a0[0] + dC[0] * (om[0] * (1.f - sg[0]) + m[0]), a0[1] + dC[1] * (om[1] * (1.f - sg[1]) + m[1]),
+                                                                    a0[2] + dC[2] * (om[2] * (1.f - sg[2]) + m[2]), a0[3] + dC[3] * (om[3] * (1.f - sg[3]) + m[3]));
+        if (ggp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
+                    make_float4(om[0] * (dW[k][0] - ch[0]), om[1] * (dW[k][1] - ch[1]), om[2] * (dW[k][2] - ch[2]), om[3] * (dW[k][3] - ch[3]));
         }
         return;
     }
@@ -313,6 +346,31 @@ __device__ __attribute__((noinline)) void bwd_epilogue4_2pass(const float* __res
                 const float4 w = get_dw(k);
                 *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
                     make_float4((1.f - m[0]) * w.x, (1.f - m[1]) * w.y, (1.f - m[2]) * w.z, (1.f - m[3]) * w.w);
+            }
+        }
+        return;
+    }
+    if (norm == CSPN_NORM_PRENORM) {  // gate_wb as given, at the pixel itself (see bwd_final_kernel)
+        float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(gbp + k * HW + (size_t)y * W + x);
+            sg[0] += q.x; sg[1] += q.y; sg[2] += q.z; sg[3] += q.w;
+        }
+        float om[4], ch[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { om[i] = 1.f - m[i]; ch[i] = dC[i] * h0[i]; }
+        if (gb) {
+            const float4 a0q = *reinterpret_cast<const float4*>(a0p + idx);
+            *reinterpret_cast<float4*>(gb + idx) = make_float4(a0q.x + dC[0] * (om[0] * (1.f - sg[0]) + m[0]), a0q.y + dC[1] * (om[1] * (1.f - sg[1]) + m[1]),
+                                                                a0q.z + dC[2] * (om[2] * (1.f - sg[2]) + m[2]), a0q.w + dC[3] * (om[3] * (1.f - sg[3]) + m[3]));
+        }
+        if (ggp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 w = get_dw(k);
+                *reinterpret_cast<float4*>(ggp + k * HW + (size_t)y * W + x) =
+                    make_float4(om[0] * (w.x - ch[0]), om[1] * (w.y - ch[1]), om[2] * (w.z - ch[2]), om[3] * (w.w - ch[3]));
             }
         }
         return;

@@ -46,7 +46,7 @@ static int check_common(const void* a, const void* b, const void* out, int n_ite
     if (!a || !b || !out) { set_error("null tensor pointer"); return CSPN_E_BADARG; }
     if (n_iter < 0) { set_error("n_iter must be >= 0 (got %d)", n_iter); return CSPN_E_BADARG; }
     if (norm < CSPN_NORM_8SUM || norm > CSPN_NORM_PRENORM) { set_error("unknown norm_type %d", norm); return CSPN_E_BADARG; }
-    if (norm > norm_max) { set_error("norm_type CSPN_NORM_PRENORM is taken by the 2D forward only"); return CSPN_E_UNSUPPORTED; }
+    if (norm > norm_max) { set_error("norm_type CSPN_NORM_PRENORM is taken by the 2D entry points only"); return CSPN_E_UNSUPPORTED; }
     if (need && (!ws || ws_bytes < need)) {
         set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return CSPN_E_WORKSPACE;
@@ -148,7 +148,7 @@ int cspn2d_backward_f32(const float* guidance, const float* blur, const float* s
     if (n_iter < 1) { set_error("backward needs n_iter >= 1 (got %d)", n_iter); return CSPN_E_BADARG; }
     if ((long long)B * H * W > 0x7fffffffLL / 9) { set_error("tensor too large for 32-bit plane indexing"); return CSPN_E_UNSUPPORTED; }
     if (!grad_out) { set_error("null grad_out"); return CSPN_E_BADARG; }
-    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_workspace(B, H, W, n_iter))) return e;
+    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_workspace(B, H, W, n_iter), CSPN_NORM_PRENORM)) return e;
     if (!grad_guidance && !grad_blur) return 0;
     return backward2d(guidance, blur, sparse, grad_out, grad_guidance, grad_blur, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream);
 }
@@ -165,7 +165,7 @@ int cspn2d_forward_history_f32(const float* guidance, const float* blur, const f
     const size_t hb = history2d_bytes(B, H, W, n_iter);
     if (hb == 0) { set_error("no history mode for B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
     if (!history || history_bytes < hb || ((uintptr_t)history & 255u)) { set_error("history buffer too small or misaligned: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
-    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, fused2d_workspace(B, H, W, n_iter))) return e;
+    if (int e = check_common(guidance, blur, out, n_iter, norm_type, ws, ws_bytes, fused2d_workspace(B, H, W, n_iter), CSPN_NORM_PRENORM)) return e;
     if (((uintptr_t)out & 15u) != 0) { set_error("output must be 16-byte aligned"); return CSPN_E_UNSUPPORTED; }
     return forward2d_history(guidance, blur, sparse, out, history, B, H, W, n_iter, norm_type, ws, (hipStream_t)stream);
 }
@@ -183,7 +183,7 @@ int cspn2d_backward_history_f32(const float* guidance, const float* blur, const 
     if (hb == 0) { set_error("no history mode for B=%d H=%d W=%d n_iter=%d", B, H, W, n_iter); return CSPN_E_UNSUPPORTED; }
     if (!grad_out) { set_error("null grad_out"); return CSPN_E_BADARG; }
     if (!history || history_bytes < hb) { set_error("history buffer too small: need %zu bytes", hb); return CSPN_E_WORKSPACE; }
-    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_history_workspace(B, H, W))) return e;
+    if (int e = check_common(guidance, blur, grad_out, n_iter, norm_type, ws, ws_bytes, backward2d_history_workspace(B, H, W), CSPN_NORM_PRENORM)) return e;
     if (!grad_guidance && !grad_blur) return 0;
     return backward2d_history(guidance, blur, sparse, grad_out, history, grad_guidance, grad_blur, B, H, W, n_iter, norm_type, ws,
                               (hipStream_t)stream);

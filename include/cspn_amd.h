@@ -44,7 +44,7 @@ extern "C" {
                               * 4: CSPN_NORM_PRENORM, cspn2d_normalize_f32, cspn2d_forward_prenorm_f32, cspn3d_backward_multi_f32; the
                               *    sited8 experiment's three entry points left the ABI (hook library, experiment builds); CSPN_ALGO_FUSED_PADDED
                               *    (what AUTO returns for W % 4 != 0; cspn2d_workspace_bytes grows accordingly for such widths);
-                              * 5: cspn_guidance_head_f32 (the producer of the path's inputs) */
+                              * 5: cspn_guidance_head_f32 (the producer of the path's inputs); CSPN_NORM_PRENORM on the 2D backward entry points */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -54,7 +54,7 @@ typedef void* cspn_stream_t;
  * fluid.layers.affinity_propagate (reference cspn_paddle/README.md:54: "should be
  * normalized in the channel dimension" by the caller, cspn_paddle/demo.py:47-49). */
 enum { CSPN_NORM_8SUM = 0, CSPN_NORM_8SUM_ABS = 1, CSPN_NORM_NONE = 2,
-       CSPN_NORM_PRENORM = 3 /* 2D forward only: `guidance` holds the reference's gate_wb (see cspn2d_normalize_f32 below) */ };
+       CSPN_NORM_PRENORM = 3 /* 2D only: `guidance` holds the reference's gate_wb (see cspn2d_normalize_f32 below) */ };
 
 /* algo: AUTO picks the fused kernel whenever the shape allows it (W % 4 == 0, 16-byte aligned output).  FUSED runs images at
  * least 256 columns wide through the assembly main loop for EVERY n_iter (round 5): n_iter = 24 k + r is one short first pass
@@ -103,7 +103,8 @@ int cspn2d_auto_algo(int B, int H, int W, int n_iter);
  * tensor in the `guidance` argument: what is left of the fold is sigma = sum_k wb_k, the centre term (1 - sigma) H_0 (cspn.py:76)
  * and the mask (cspn.py:81) -- no abs-sum, no reciprocal, no edge patching, aligned loads.  Results: those of CSPN_NORM_8SUM /
  * _8SUM_ABS on the raw guidance up to the rounding of the division (<= 1e-6 relative; NaN where sum |G| = 0, as the reference).
- * Every shape and n_iter the forward takes; no backward (the gradient w.r.t. wb is the producer's to chain: use the raw contract).
+ * Every shape and n_iter the forward takes.  Backward (ABI 5): cspn2d_backward_f32 / _history_f32 with CSPN_NORM_PRENORM return dL/d(wb) in grad_guidance --
+ * dL/dwb_k(p) = (1 - m)(dW'_k - dC H_0)(p), no normalisation chain, no scatter -- and dL/d(blur_depth); chaining dL/d(wb) into the head is the producer's.
  * cspn2d_normalize_f32 is that producer epilogue as a stand-alone kernel (norm_type 8SUM or 8SUM_ABS; tests, A/B timing):
  * 36 B read + 32 B written per pixel.  cspn2d_forward_prenorm_f32 = cspn2d_forward_f32 with norm_type CSPN_NORM_PRENORM. */
 int cspn2d_normalize_f32(const float* guidance, float* wb, int B, int H, int W, int norm_type, cspn_stream_t stream);
@@ -115,7 +116,8 @@ int cspn2d_forward_prenorm_f32(const float* wb, const float* blur, const float* 
  *   grad_out      [B,1,H,W]  dL/d(out)
  *   grad_guidance [B,8,H,W]  dL/d(guidance), or NULL to skip
  *   grad_blur     [B,1,H,W]  dL/d(blur_depth) (as level-0 value and as H_0 of the centre / mask terms), or NULL to skip
- * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1.  Fast path (two sweeps of the assembly ring that keep every fourth
+ * sparse_depth gets no gradient (only its sign is used, cspn.py:64).  n_iter >= 1.  norm_type: 8SUM, 8SUM_ABS, NONE, or PRENORM (then `guidance` = gate_wb and
+ * grad_guidance = dL/d(gate_wb), see above).  Fast path (two sweeps of the assembly ring that keep every fourth
  * level + one recomputing final pass): W >= 256, W % 4 == 0, n_iter = 4, 8 .. 24 (24 only until round 5); everything else runs one launch per step.
  * For n_iter < 24 both sweeps still run the full 24-level ring and discard the levels beyond n_iter (the checkpoint of level n_iter is stored when the row passes it;
  * `out` briefly holds level 24 before the level-n_iter plane overwrites it): correct, but their cost does not shrink with n_iter (profiles/r05_backward_niter.jsonl),

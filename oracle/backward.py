@@ -22,15 +22,22 @@ def _shift(a, dy, dx):
 
 
 def cspn2d_backward_oracle(guidance, blur, sparse, grad_out, n_iter, norm_type="8sum", dtype=np.float32):
+    """-> (out, dL/dguidance, dL/dblur_depth).  norm_type 'prenorm': `guidance` is the reference's gate_wb (cspn.py:85-144, cropped to the
+    image), used as given at the pixel itself -- the gradient w.r.t. it is dL/dw of the derivation above, the chain through the
+    normalisation and the neighbour-sited gather is the producer's (pinned by tests/golden/cspn2d_grad_prenorm_golden.npz: the unmodified
+    reference's autograd with the returned gate_wb as the differentiated tensor)."""
     g = np.asarray(guidance, dtype)
     h0 = np.asarray(blur, dtype)[:, 0]
     go = np.asarray(grad_out, dtype)[:, 0]
     B, _, H, W = g.shape
     gt = np.abs(g) if norm_type == "8sum_abs" else g
     with np.errstate(all="ignore"):
-        G = np.stack([_shift(gt[:, k], DY[k], DX[k]) for k in range(8)], 1)      # [B,8,H,W]
-        S = np.abs(G).sum(1)
-        w = G / S[:, None]
+        if norm_type == "prenorm":
+            G, S, w = None, None, g
+        else:
+            G = np.stack([_shift(gt[:, k], DY[k], DX[k]) for k in range(8)], 1)      # [B,8,H,W]
+            S = np.abs(G).sum(1)
+            w = G / S[:, None]
         sigma = w.sum(1)
         m = np.sign(np.asarray(sparse, dtype)[:, 0]) if sparse is not None else np.zeros_like(h0)
         om = 1 - m
@@ -58,6 +65,8 @@ def cspn2d_backward_oracle(guidance, blur, sparse, grad_out, n_iter, norm_type="
             A = An.astype(dtype)
         dw = om[:, None] * (dW - (dC * h0)[:, None])
         grad_blur = A + dC * (om * (1 - sigma) + m)
+        if norm_type == "prenorm":
+            return hs[-1][:, None], dw.astype(np.float32), grad_blur[:, None].astype(np.float32)
         T1 = (dw * G).sum(1)
         dG = dw / S[:, None] - np.sign(G) * (T1 / (S * S))[:, None]
         gg = np.zeros_like(g)

@@ -56,6 +56,30 @@ def reference_grads(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, nor
     return out.detach(), gg, gh
 
 
+def reference_grads_wrt_gate_wb(guidance, blur_depth, sparse_depth, grad_out, n_iter=24, norm_type="8sum"):
+    """-> (gate_wb [B,8,H,W], out, dL/dgate_wb [B,8,H,W], dL/dblur_depth) of L = sum(out * grad_out) by torch autograd through the UNMODIFIED
+    reference forward, differentiated with respect to the tensor its affinity_normalization RETURNS (cspn.py:85-144; also the source of
+    gate_sum, :139): the method is wrapped on the instance so that the returned gate_wb keeps its gradient -- the reference file is
+    untouched.  Cropped to the image like the reference crops the product (cspn.py:72): nothing outside it reaches the output."""
+    ref = load_reference_module()
+    m = ref.Affinity_Propagate(n_iter, 3, norm_type)
+    g = guidance.clone().requires_grad_(True)
+    h = blur_depth.clone().requires_grad_(True)
+    orig, cap = m.affinity_normalization, {}
+
+    def keeping(gd):
+        wb, gs = orig(gd)
+        wb.retain_grad()
+        cap["wb"] = wb
+        return wb, gs
+    m.affinity_normalization = keeping
+    with cuda_is_identity():
+        out = m(g, h, sparse_depth)
+        out.backward(grad_out)
+    wb = cap["wb"]
+    return (wb.detach()[:, :, 0, 1:-1, 1:-1].contiguous(), out.detach(), wb.grad[:, :, 0, 1:-1, 1:-1].contiguous(), h.grad.detach())
+
+
 def reference_gate_wb(guidance, norm_type="8sum"):
     """-> (gate_wb [B,8,H,W], gate_sum [B,1,H,W]) of /root/reference/cspn_pytorch/models/cspn.py:85-144 (affinity_normalization),
     gate_wb cropped to the image like the reference crops the product at cspn.py:72: the consumer-sited, normalised weights the

@@ -202,3 +202,77 @@ def test_backward_norm_none_on_the_checkpointed_path_vs_torch_autograd(sp):
     gg, gh = cspn_amd.cspn2d_backward(g, h, s, go, N, "none")
     assert _check(gg.cpu().numpy(), g0.grad.cpu().numpy())
     assert _check(gh.cpu().numpy(), h0.grad.cpu().numpy())
+
+
+# ---- the pre-normalised input contract (CSPN_NORM_PRENORM, round 6): gradient w.r.t. the reference's gate_wb ------------------------------
+def _golden_prenorm():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cspn2d_grad_prenorm_golden.npz"))
+    for n in sorted({k.split("/")[0] for k in z.files}):
+        yield n, {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")}
+
+
+def test_prenorm_backward_oracle_vs_reference_autograd():
+    """oracle/backward.py with norm 'prenorm' against the unmodified reference's autograd gradient w.r.t. the gate_wb its
+    affinity_normalization returned (tests/golden/make_grad_prenorm_golden.py)"""
+    n = 0
+    for name, c in _golden_prenorm():
+        B, H, W, N = (int(v) for v in c["meta"])
+        o, gg, gh = cspn2d_backward_oracle(c["gate_wb"], c["blur"], c.get("sparse"), c["grad_out"], N, "prenorm")
+        assert _err(o, c["out"]) <= 1e-5 and _err(gg, c["grad_gate_wb"]) <= 1e-5 and _err(gh, c["grad_blur"]) <= 1e-5, name
+        n += 1
+    assert n == 7
+
+
+def test_prenorm_backward_oracle_vs_live_reference():
+    from oracle import ref_harness
+    if not ref_harness.available():
+        pytest.skip("reference tree not present")
+    gen = torch.Generator().manual_seed(31)
+    g = torch.randn(1, 8, 7, 9, generator=gen)
+    h = torch.rand(1, 1, 7, 9, generator=gen) * 5
+    s = (torch.rand(1, 1, 7, 9, generator=gen) < 0.2).float() * 2.0
+    go = torch.randn(1, 1, 7, 9, generator=gen)
+    wb, o, gwb, gh = ref_harness.reference_grads_wrt_gate_wb(g, h, s, go, 5, "8sum_abs")
+    ro, rgg, rgh = cspn2d_backward_oracle(wb.numpy(), h.numpy(), s.numpy(), go.numpy(), 5, "prenorm")
+    assert _err(ro, o.numpy()) <= 1e-5 and _err(rgg, gwb.numpy()) <= 1e-5 and _err(rgh, gh.numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_prenorm_backward_vs_reference_autograd_goldens():
+    import cspn_amd
+    for name, c in _golden_prenorm():
+        B, H, W, N = (int(v) for v in c["meta"])
+        t = {k: torch.from_numpy(v).cuda() for k, v in c.items() if k != "meta"}
+        gg, gh = cspn_amd.cspn2d_backward(t["gate_wb"], t["blur"], t.get("sparse"), t["grad_out"], N, "prenorm")
+        torch.cuda.synchronize()
+        assert _check(gg.cpu().numpy(), c["grad_gate_wb"]), name
+        assert _check(gh.cpu().numpy(), c["grad_blur"]), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,N,sp", [(2, 37, 53, 24, True), (3, 20, 256, 12, False), (2, 41, 260, 24, True), (1, 89, 300, 24, False),
+                                        (1, 3, 256, 24, False), (2, 33, 516, 16, True), (1, 30, 40, 30, True), (2, 70, 512, 24, True)])
+def test_hip_prenorm_backward_vs_oracle_and_through_autograd(B, H, W, N, sp):
+    """every backward path (one launch per step; the two ring sweeps + recomputing final pass, n_iter = 4 .. 24; training mode with kept
+    checkpoints) with the reference's gate_wb as the input, against the numpy restatement -- and the chain rule closed: the gradient of the
+    raw contract = this gradient pushed through the stand-alone normalisation by torch autograd"""
+    import cspn_amd
+    g, h, s = make_inputs(B, H, W, seed=B + H + W + N, sparse=sp, neg=sp)
+    go = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(5))
+    wb = cspn_amd.cspn2d_normalize(g.cuda(), "8sum")
+    sd = None if s is None else s.cuda()
+    _, rgg, rgh = cspn2d_backward_oracle(wb.cpu().numpy(), h.numpy(), None if s is None else s.numpy(), go.numpy(), N, "prenorm")
+    gg, gh = cspn_amd.cspn2d_backward(wb, h.cuda(), sd, go.cuda(), N, "prenorm")
+    assert _check(gg.cpu().numpy(), rgg) and _check(gh.cpu().numpy(), rgh)
+    wbd, hd = wb.clone().requires_grad_(True), h.cuda().requires_grad_(True)
+    out = cspn_amd.propagate_prenorm(wbd, hd, sd, N)
+    ref = cspn_amd.cspn2d_forward(wb, h.cuda(), sd, N, "prenorm")
+    assert float((out.detach() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    out.backward(go.cuda())
+    assert _check(wbd.grad.cpu().numpy(), rgg) and _check(hd.grad.cpu().numpy(), rgh)
+    if cspn_amd.cspn2d_history_bytes(B, H, W, N) > 0:   # training mode == recomputing path, bit for bit
+        assert torch.equal(wbd.grad, gg) and torch.equal(hd.grad, gh)
+    # only one input needs a gradient
+    hd2 = h.cuda().requires_grad_(True)
+    cspn_amd.propagate_prenorm(wb, hd2, sd, N).backward(go.cuda())
+    assert _check(hd2.grad.cpu().numpy(), rgh)

@@ -67,6 +67,14 @@ def test_emulated_history_variant_writes_its_levels(every):
     assert nanmis == 0 and err <= 1e-4
 
 
+@pytest.mark.parametrize("sparse", [False, True])
+def test_emulated_history_variant_of_the_prenorm_contract(sparse):
+    """cfg hist with norm 3 (round 6: the history sweep of the backward of CSPN_NORM_PRENORM): checkpoints and folded planes against the oracle"""
+    os.chdir(ROOT)
+    err, nanmis, _, _ = run_case(2, 11, 304, 4, 3, sparse, False, seed=3, verbose=False, hist=True, hist_every=K.HIST_EVERY, zero_patch=True)
+    assert nanmis == 0 and err <= 1e-4
+
+
 def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
     """cfg adj: the backward's adjoint sweep A_t(p) = sum_k w'_k(p - off_k) A_{t+1}(p - off_k) run by the ring kernel over the
     folded planes (neighbour-sited, channel order reversed), every level checked"""
@@ -123,8 +131,8 @@ def test_emulated_adjoint_variant_vs_numpy_adjoint_recursion():
 
 
 def test_generated_include_is_current_and_hazard_free(tmp_path, monkeypatch):
-    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 31 variants (16 forward: 4 norms incl. round 5's
-    prenorm x mask x continuation pass, 8 short first passes (n < 24 iterations), 6 history, the adjoint sweep) -- and every one of them passes the static hazard rules (K.build
+    """the committed cspn2d_tsw_gen.inc is byte for byte what the generator emits -- ALL 33 variants (16 forward: 4 norms incl. round 5's
+    prenorm x mask x continuation pass, 8 short first passes (n < 24 iterations), 8 history (round 6: prenorm too), the adjoint sweep) -- and every one of them passes the static hazard rules (K.build
     raises on a hazard)"""
     from tools.tswgen import emit
     out = tmp_path / "gen.inc"
@@ -132,7 +140,7 @@ def test_generated_include_is_current_and_hazard_free(tmp_path, monkeypatch):
     emit.main()
     new = out.read_text()
     old = open(os.path.join(ROOT, "cspn_amd", "csrc", "cspn2d_tsw_gen.inc")).read()
-    assert new.count("#define TSW_ASM_") == 31
+    assert new.count("#define TSW_ASM_") == 33
     assert new == old, "cspn_amd/csrc/cspn2d_tsw_gen.inc is stale: python -m tools.tswgen.emit"
 
 

@@ -154,7 +154,7 @@ class Gen(object):
         self.xstubs, self.xstub_of = [], {}
         self.given = self.norm in (2, 3)   # coefficients are used as given, centre-sited (3: with the centre term, 2: without)
         if self.norm == 3:
-            assert not self.adj and not self.hist and not self.s8
+            assert not self.adj and not self.s8
         self.sited = (not self.given or self.adj) and not self.s8   # guidance plane k is read at (y + dy_k, x + dx_k)
         assert cfg.get("n_iter", 24) == 24
         self.stubs = []

@@ -124,7 +124,7 @@ def run_case(B, H, W, n_wg, norm=0, sparse=False, hin=False, seed=0, zero_patch=
         worst = 0.0
         for i in range(npl):
             lv = (i + 1) * hist_every
-            r = O.cspn2d_oracle(g, blur, sp, lv, ["8sum", "8sum_abs", "none"][norm])
+            r = O.cspn2d_oracle(g, blur, sp, lv, ["8sum", "8sum_abs", "none", "8sum"][norm])
             assert np.array_equal(np.isnan(hb[i]), np.isnan(r)), "history level %d: NaN pattern" % lv
             worst = max(worst, float(np.nanmax(np.abs(hb[i] - r)) / np.nanmax(np.abs(r))))
         if verbose:
