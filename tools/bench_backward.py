@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--vol3d", action="store_true", help="the 3D backward (Paddle contract) at BASELINE config 5's volume")
     ap.add_argument("--n-iter", type=int, default=24, help="2D: iterations (multiples of 4 up to 24 take the checkpointed ring path)")
+    ap.add_argument("--norm", default="8sum", choices=["8sum", "8sum_abs", "none", "prenorm"],
+                    help="prenorm (round 6): the guidance is normalised once, outside the timed region (cspn2d_normalize_f32); the timed calls take the reference's gate_wb")
     a = ap.parse_args()
     if a.vol3d:
         return vol3d(a)
@@ -60,19 +62,28 @@ def main():
     if a.sparse:
         s = (torch.rand(B, 1, H, W, generator=gen, device="cuda") < 500.0 / (H * W)).float() * (h + 0.1)
     go = torch.randn(B, 1, H, W, generator=gen, device="cuda")
+    if a.norm == "prenorm":
+        g = cspn_amd.cspn2d_normalize(g, "8sum")
+    elif a.norm == "none":
+        g = g.abs() / g.abs().sum(1, keepdim=True)
     for _ in range(3):
-        cspn_amd.cspn2d_backward(g, h, s, go, N, "8sum")
+        cspn_amd.cspn2d_backward(g, h, s, go, N, a.norm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        cspn_amd.cspn2d_backward(g, h, s, go, N, "8sum")
+        cspn_amd.cspn2d_backward(g, h, s, go, N, a.norm)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     # a training step through the module (forward + backward), with and without the level history kept by the forward
     train = {}
     for keep in (True, False):
-        m = cspn_amd.Affinity_Propagate(N, 3, "8sum")
-        m.keep_history = keep
+        if a.norm in ("8sum", "8sum_abs"):
+            m = cspn_amd.Affinity_Propagate(N, 3, a.norm)
+            m.keep_history = keep
+        elif a.norm == "prenorm":
+            m = lambda gd, hd, sd, keep=keep: cspn_amd.propagate_prenorm(gd, hd, sd, N, keep_history=keep)   # noqa: E731
+        else:
+            break
         gr, hr = g.clone().requires_grad_(True), h.clone().requires_grad_(True)
         for _ in range(3):
             m(gr, hr, s).backward(go)
@@ -85,7 +96,7 @@ def main():
         train["keep_history" if keep else "recompute"] = round((time.perf_counter() - t0) / a.steps * 1e3, 3)
     px = B * H * W
     alg = px * (80 if a.sparse else 76)
-    print(json.dumps({"op": "cspn2d_backward_f32", "B": B, "H": H, "W": W, "n_iter": N, "sparse": a.sparse,
+    print(json.dumps({"op": "cspn2d_backward_f32", "B": B, "H": H, "W": W, "n_iter": N, "sparse": a.sparse, "norm": a.norm,
                       "ms_per_call": round(ms, 3), "Mpix_iters_per_s": round(px * N / ms / 1e3, 1),
                       "algorithmic_bytes": alg, "roofline_frac": round(alg / (ms * 1e-3) / 8e12, 4),
                       "train_step_fwd_bwd_ms": train,
