@@ -148,7 +148,7 @@ def guidance_heads(x, weight_guidance, weight_blur=None, oheight=0, owidth=0, no
     multiplies the structurally zero taps.  x [B,C,h,w]; weight_guidance = layer6.conv1.weight [8,C,3,3]; weight_blur = layer5.conv1.weight [1,C,3,3] or None.
     norm_type None: -> (guidance [B,8,H,W], blur [B,1,H,W] | None), bit-compatible inputs of Affinity_Propagate(..., norm_type)(guidance, blur, sparse).
     norm_type '8sum' | '8sum_abs': the guidance comes back normalised -- gate_wb of affinity_normalization (cspn.py:85-144) -- for
-    cspn2d_forward(gate_wb, blur, sparse, n_iter, 'prenorm'): no stand-alone normalisation pass.  Forward only (inference / the frozen-head case)."""
+    cspn2d_forward(gate_wb, blur, sparse, n_iter, 'prenorm') / cspn_amd.propagate_prenorm.  The head itself is forward only (inference / the frozen-head case)."""
     lib = _lib.load()
     xx = _prep(x, "x")
     B, C, h, w = xx.shape
