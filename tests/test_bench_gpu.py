@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
-LEGS = ("backward2d_kitti_B64", "prenorm_kitti_B64", "config4_kitti_sparse_B32", "config2_nyu_B16", "config3_as_written_share_B8", "config1_plumbing_B1",
+LEGS = ("backward2d_kitti_B64", "prenorm_kitti_B64", "head_kitti_B64", "config4_kitti_sparse_B32", "config2_nyu_B16", "config3_as_written_share_B8", "config1_plumbing_B1",
         "config5_vol3d_B4")
 
 
@@ -38,7 +38,10 @@ def test_driver_line_carries_every_config():
         assert "error" not in leg, (name, leg.get("error"))
         assert leg["parity_checked"]["ok"] is True, (name, leg["parity_checked"])
         assert leg["steps"] == 3 and leg["ms_per_step"] > 0 and leg["roofline"]["device_ms_per_launch"] > 0
-        assert 0 < leg["roofline"]["frac"] < 1 and leg["roofline"]["bound"] == "hbm"
+        assert 0 < leg["roofline"]["frac"] < 1 and leg["roofline"]["bound"] == ("mfma" if name.startswith("head_") else "hbm")
     assert d["configs"]["config5_vol3d_B4"]["parity_checked"]["oracle_full_volume"]["voxels"] == 32 * 160 * 608
     assert d["configs"]["config4_kitti_sparse_B32"]["roofline"]["algorithmic_bytes_per_launch"] == 32 * 304 * 1216 * 44
     assert d["configs"]["backward2d_kitti_B64"]["roofline"]["algorithmic_bytes_per_launch"] == 64 * 304 * 1216 * 76
+    head = d["configs"]["head_kitti_B64"]   # round 6: the producer of config 3's inputs, priced against the fp32 peak
+    assert head["roofline"]["peak"] == 157.3 and head["roofline"]["unit"] == "TFLOP/s" and head["roofline"]["algorithmic_flop_per_launch"] == 2.0 * 81 * 64 * 64 * 152 * 608
+    assert head["head_plus_forward_ms"] > head["roofline"]["device_ms_per_launch"]
