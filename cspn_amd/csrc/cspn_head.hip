@@ -32,17 +32,24 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // with x00 = the pixel, x01 its right, x10 its lower, x11 its lower right neighbour (zero beyond the image / the narrowed output).
 //   * The right neighbour comes from the neighbouring lane (DPP wave_shl:1; lane 63 only serves lane 62: segments of 63 owned columns).
 //   * The feature map is read ONCE, from HBM: ~2 us of latency per access against ~0.2 us of arithmetic per channel.  A wave keeps the three feature rows of
-//     the NEXT 8 channels on their way into its own LDS slots by LDS-DMA (global_load_lds_dword: no VGPR in flight, no other wave involved, hence no barrier):
-//     slot c % 8 is requested again right after channel c was consumed, and waited for -- a counted s_waitcnt vmcnt -- 8 channels later.
+//     the NEXT 4 channels on their way into its own LDS slots by LDS-DMA (global_load_lds_dword: no VGPR in flight, no other wave involved, hence no barrier):
+//     slot c % 4 is requested again right after channel c was consumed, and waited for -- a counted s_waitcnt vmcnt -- 4 channels later.
 //   * Every mask lives in a READ ADDRESS: each slot has a fourth row that nothing ever writes (zeros); a lane whose column, or a wave whose row, is outside
 //     reads that row.  Nothing but 3 address adds, 4 LDS reads, 4 DPP moves and the 81 FMAs runs per channel.
 //   * A channel's 81 weights are scalar loads ([c][o][ky][kx], 84-float records): with the loop state they fit the 102 SGPRs without spills.  (The first
 //     versions of this kernel -- one row per wave, masks as selects, 90 weight dwords -- spent a third of their issue slots on v_readlane / v_cndmask around
 //     spilled scalars: 1.09 ms where the arithmetic alone took 0.69, profiles/r06_head.md.)
 #ifndef HEAD_ABL
-#define HEAD_ABL 0   // timing builds only (tools/r06/build_abl_head.sh): 1 = no feature reads, 2 = one channel's weights for all, 4 = 4 of the 9 output planes
+#define HEAD_ABL 0   // timing builds only (tools/r06/build_abl_head.sh): 1 = no feature reads, 2 = one channel's weights for all, 4 = 4 of the 9 output planes, 8 = every feature request reads channel 0 or 1 (from L2), 16 = nothing stored, 32 = LDS reads of stale slots without requests, 64 = requests without LDS reads
 #endif
-constexpr int RAW_DEPTH = 8;
+#ifndef HEAD_DEPTH
+#define HEAD_DEPTH 4     // channels in flight per wave: 2, 3, 4, 6, 8 measure the same within 1.5 % (4 and 3 best): the feed is a throughput cost, not a latency
+                         // (A/B builds: tools/r06/build_abl_head.sh 0 "-DHEAD_DEPTH=8" d8)
+#endif
+#ifndef HEAD_OCC
+#define HEAD_OCC 5       // workgroups (= waves per SIMD) the register budget is set for
+#endif
+constexpr int RAW_DEPTH = HEAD_DEPTH;
 constexpr int WREC = 84;     // floats per channel in the raw kernel's weight records (81 + pad: 16-byte multiples)
 __global__ __launch_bounds__(256) void head_rawpack_kernel(const float* __restrict__ w6, const float* __restrict__ w5, float* __restrict__ wr, int C) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void head_rawpack_kernel(const float* __restri
 }
 
 template <bool SITED>
-__global__ __launch_bounds__(256) void head_raw_kernel(const float* __restrict__ x, const float* __restrict__ wr, float* __restrict__ gout,
+__global__ __launch_bounds__(256, HEAD_OCC) void head_raw_kernel(const float* __restrict__ x, const float* __restrict__ wr, float* __restrict__ gout,
                                                         float* __restrict__ bout, int C, int h, int w, int H, int W, int B) {
     __shared__ float xs[4][RAW_DEPTH][4][64];            // [wave][slot][feature row i0, i0 + 1, i0 + 2, zeros][lane]
     const int wq = (w + 62) / 63, hp = (h + 1) / 2;
@@ -82,9 +89,9 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const float* __restrict__
         const float* row0 = x + (size_t)b * C * hw + (size_t)i0 * w;          // scalar: the row's address
         const unsigned d1 = i0 + 1 < h ? 4u * w : 0u, d2 = i0 + 2 < h ? 4u * w : 0u;   // (rows beyond the image: the row before again; never read back)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        auto request = [&](int c) {
-            const unsigned dst = lds0 + (unsigned)(c % RAW_DEPTH) * 1024u;
-            const float* q0 = row0 + (size_t)c * hw;
+        auto request = [&](int c, unsigned slot_off) {
+            const unsigned dst = lds0 + slot_off;
+            const float* q0 = row0 + (size_t)((HEAD_ABL & 8) ? (c & 1) : c) * hw;   // (8: every request reads channel 0 / 1: L2-resident)
             const float* q1 = (const float*)((const char*)q0 + d1);
             const float* q2 = (const float*)((const char*)q1 + d2);
             asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\ts_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
@@ -96,15 +103,15 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const float* __restrict__
             return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
         };
         const int pre = C < RAW_DEPTH ? C : RAW_DEPTH;
-        if (!(HEAD_ABL & 1)) for (int c = 0; c < pre; ++c) request(c);
+        if (!(HEAD_ABL & (1 | 32))) for (int c = 0; c < pre; ++c) request(c, (unsigned)c * 1024u);
+        unsigned so = 0;                                                          // slot of channel c: (c mod RAW_DEPTH) KiB
         for (int c = 0; c < C; ++c) {
-            if (HEAD_ABL & 1) ;
+            if (HEAD_ABL & (1 | 32)) ;
             else if (c + RAW_DEPTH <= C) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RAW_DEPTH - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the last RAW_DEPTH - 1 channels: the queue drains)
             float u0, u1, u2;
-            if (HEAD_ABL & 1) { u0 = (float)(lane + c); u1 = (float)(lane ^ c); u2 = (float)(lane - c); }
+            if (HEAD_ABL & (1 | 64)) { u0 = (float)(lane + c); u1 = (float)(lane ^ c); u2 = (float)(lane - c); }
             else {
-                const unsigned so = (unsigned)(c % RAW_DEPTH) * 1024u;
                 u0 = lds(va0 + so); u1 = lds(va1 + so); u2 = lds(va2 + so);
             }
             const float e0 = right(u0), e1 = right(u1), e2 = right(u2);
@@ -123,10 +130,12 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const float* __restrict__
                 P11[o] = __builtin_elementwise_fma(f2{k[6], k[6]}, xb, P11[o]);
                 P11[o] = __builtin_elementwise_fma(f2{k[8], k[8]}, xd, P11[o]);
             }
-            if (!(HEAD_ABL & 1) && c + RAW_DEPTH < C) request(c + RAW_DEPTH);   // (its slot's values are in registers: the FMAs above consumed the reads)
+            if (!(HEAD_ABL & (1 | 32)) && c + RAW_DEPTH < C) request(c + RAW_DEPTH, so);   // (its slot's values are in registers: the FMAs above consumed the reads)
+            so = so + 1024u == RAW_DEPTH * 1024u ? 0u : so + 1024u;
         }
     }
     if (j >= w || lane == 63 || 2 * j >= W) return;
+    if ((HEAD_ABL & 16) && C > 0) return;
     const int X0 = 2 * j;
 #pragma unroll
     for (int o = 0; o < 9; ++o) {

@@ -1,6 +1,6 @@
 #!/bin/bash
-# the raw guidance head: product and the timing builds, alternating, one box
+# the raw guidance head: product and the timing builds (tools/r06/build_abl_head.sh), alternating, one box
 for r in 1 2; do
   python tools/r06/time_head.py 2>/dev/null | tail -1
-  for n in 1 2 3 7; do CSPN_AMD_LIB=$PWD/cspn_amd/abl/libcspn_head_$n.so python tools/r06/time_head.py 2>/dev/null | tail -1; done
+  for f in cspn_amd/abl/libcspn_head_*.so; do CSPN_AMD_LIB=$PWD/$f python tools/r06/time_head.py 2>/dev/null | tail -1; done
 done
