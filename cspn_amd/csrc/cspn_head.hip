@@ -149,15 +149,19 @@ __global__ __launch_bounds__(256, HEAD_OCC) void head_raw_kernel(const float* __
             const int Y0 = 2 * (i0 + half);
             if (i0 + half >= h) continue;
             const float p00 = half ? P00[o].y : P00[o].x, p01 = half ? P01[o].y : P01[o].x, p10 = half ? P10[o].y : P10[o].x, p11 = half ? P11[o].y : P11[o].x;
-            auto put = [&](int Y, int X, float v) {
-                if (Y >= H || X >= W) return;                       // (the narrowed output)
-                const int yp = Y - sy, xp = X - sx;
-                if (!SITED || (yp >= 0 && yp < H && xp >= 0 && xp < W)) dst[(size_t)yp * W + xp] = v;
+            // a pixel's two outputs of a row are neighbours in memory (also when shifted): one 8-byte store where both exist
+            auto put2 = [&](int Y, float va, float vb) {
+                if (Y >= H) return;                                  // (the narrowed output)
+                const int yp = Y - sy, xa = X0 - sx;
+                if (SITED && (yp < 0 || yp >= H)) return;
+                float* d = dst + (size_t)yp * W + xa;
+                const bool oka = xa >= 0 && xa < W, okb = X0 + 1 < W && xa + 1 >= 0 && xa + 1 < W;
+                if (oka && okb) { const f2 v = f2{va, vb}; __builtin_memcpy(d, &v, 8); }
+                else if (oka) d[0] = va;
+                else if (okb) d[1] = vb;
             };
-            put(Y0, X0, p00);
-            put(Y0, X0 + 1, p01);
-            put(Y0 + 1, X0, p10);
-            put(Y0 + 1, X0 + 1, p11);
+            put2(Y0, p00, p01);
+            put2(Y0 + 1, p10, p11);
         }
     }
 }
