@@ -79,6 +79,9 @@ LEGEND = {
     "k_head": "head_raw_kernel (cspn_head.hip): packed fp32 FMAs (no fp32 MFMA gain on gfx950: v_mfma_f32 and v_pk_fma_f32 share the 157.3 TFLOP/s peak), feature "
               "rows by LDS-DMA 8 channels ahead, weights as scalar operands",
     "oracle_head": "oracle/oracle.py guidance_head_oracle (numpy, fp64 accumulation), pinned to the unmodified reference's modules (tests/golden/head_golden.npz)",
+    "field_training_mode": "backward leg, `training_mode`: cspn2d_forward_history_f32 (the forward that also keeps H_4 .. H_20 and the folded planes: what "
+                           "cspn_amd.Affinity_Propagate runs when an input requires grad) and cspn2d_backward_history_f32 (adjoint sweep + final pass from that history), "
+                           "device ms per call by HIP events; `same_gradients`: bitwise equal to the recomputing call's",
     "bwd": "cspn2d_backward_f32: gradient of BASELINE config 3's forward w.r.t. guidance and blur_depth (reference train.py:196-198), 76 B/pixel algorithmic",
 }
 BACKBONE_PARAMS = 256_078_272  # resnet50-CSPN fp32 parameter count (probed)
@@ -556,6 +559,35 @@ def leg_backward2d(lib, _lib, dev, g, h, s, n_iter, norm_name, steps, warmup, pr
 
     elapsed, dev_ms = timed_leg(step, stream, steps, warmup, prewarm_s)
     ms = sum(dev_ms) / len(dev_ms)
+    # training mode (what cspn_amd.Affinity_Propagate does when an input requires grad): the forward keeps its checkpoints + folded planes (13 planes),
+    # the backward starts from them -- no history sweep inside the backward call
+    train = None
+    try:
+        hb = lib.cspn2d_history_bytes(B, H, W, n_iter)
+        if hb:
+            hist = torch.empty(hb, dtype=torch.uint8, device=dev)
+            out = torch.empty_like(h)
+            wsf_bytes = lib.cspn2d_workspace_bytes(B, H, W, n_iter)
+            wsf = torch.empty(max(wsf_bytes, 1), dtype=torch.uint8, device=dev)
+            wsh_bytes = lib.cspn2d_backward_history_workspace_bytes(B, H, W, n_iter)
+            wsh = torch.empty(max(wsh_bytes, 1), dtype=torch.uint8, device=dev)
+            gg2, gh2 = torch.empty_like(g), torch.empty_like(h)
+            sp = s.data_ptr() if s is not None else None
+
+            def fwd_hist():
+                _lib.check(lib.cspn2d_forward_history_f32(g.data_ptr(), h.data_ptr(), sp, out.data_ptr(), hist.data_ptr(), hb, B, H, W, n_iter, norm,
+                                                          wsf.data_ptr(), wsf_bytes, stream.cuda_stream), "cspn2d_forward_history_f32")
+
+            def bwd_hist():
+                _lib.check(lib.cspn2d_backward_history_f32(g.data_ptr(), h.data_ptr(), sp, go.data_ptr(), hist.data_ptr(), hb, gg2.data_ptr(), gh2.data_ptr(),
+                                                           B, H, W, n_iter, norm, wsh.data_ptr(), wsh_bytes, stream.cuda_stream), "cspn2d_backward_history_f32")
+            _, f_ms = timed_leg(fwd_hist, stream, steps, min(warmup, 5), 0.0)
+            _, b_ms = timed_leg(bwd_hist, stream, steps, min(warmup, 5), 0.0)
+            train = {"forward_keeping_history_ms": round(sum(f_ms) / len(f_ms), 4), "backward_from_history_ms": round(sum(b_ms) / len(b_ms), 4),
+                     "same_gradients": bool(torch.equal(gg2, gg) and torch.equal(gh2, gh))}
+            del hist, out, wsf, wsh, gg2, gh2
+    except Exception as ex:   # noqa: BLE001
+        train = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:120])}
     from oracle.backward import cspn2d_backward_oracle
     _, rg, rh = cspn2d_backward_oracle(g[:1].cpu().numpy(), h[:1].cpu().numpy(), None if s is None else s[:1].cpu().numpy(),
                                        go[:1].cpu().numpy(), n_iter, norm_name)
@@ -574,6 +606,7 @@ def leg_backward2d(lib, _lib, dev, g, h, s, n_iter, norm_name, steps, warmup, pr
                      "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": source,
                      "algorithmic_bytes_per_launch": alg, "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4)},
+        "training_mode": train,
     }
 
 
