@@ -12,7 +12,7 @@
 // CSPN_NORM_PRENORM (round 6): `guidance` is the reference's gate_wb (cspn.py:85-144), w_k(p) = wb_k(p) at the pixel itself: the chain ends at
 //           dL/dwb_k = (1-m)(dW'_k - dC H_0),   dL/dH_0 = A_0 + dC ((1-m)(1 - sum_k wb_k) + m).
 // 24-iteration passes on images the ring kernel takes: two sweeps of that kernel (forward keeping H_4, H_8 .. H_20 and the folded
-// coefficients, adjoint keeping A_20 .. A_4) + bwd_final_ck_kernel, which recomputes the levels in between tile by tile.
+// coefficients, adjoint keeping A_20 .. A_4) + bwd_final_mx_kernel, which recomputes the levels in between tile by tile.
 // Everything else: fold + one launch per step for both recursions (every level kept) + bwd_final_kernel.
 #include <cstdlib>
 #include <type_traits>
@@ -754,6 +754,7 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
     auto seg_h = [&](int j) { return ld(j == 0 ? blur : hh + (size_t)(j - 1) * total); };                       // H_{4j}
     auto seg_a = [&](int j) { return ld(j == NSEG - 1 ? gout : ah + (size_t)(NSEG - 2 - j) * total); };         // A_{4j+4}
     const bool wave_in_tile_rows = (ry & ~3) >= CK && (ry & ~3) < CK_ROWS - CK;
+#ifndef BWD_FINAL_MERGED   // the product: the adjoint levels of a segment first, then its H steps (7 barriers per segment, one dependent chain at a time)
     float4 nh = seg_h(0), na = seg_a(0);   // the checkpoints are requested one segment ahead
     int par = 0;
     auto segments = [&](auto masked) {
@@ -845,6 +846,133 @@ __global__ __launch_bounds__(CK_ROWS * CK_GR) __attribute__((amdgpu_waves_per_eu
             }
         }
     };
+#else
+    // Round 6 A/B build (-DBWD_FINAL_MERGED; parity-green, 3 % SLOWER: profiles/r06_backward_merge_ab.md): the adjoint steps of segment j + 1 run INSIDE the H
+    // steps of segment j -- two independent chains per iteration for the three waves of a SIMD to interleave, one LDS round trip and ONE barrier for both (4 per
+    // segment instead of 7).  A_{s'+4} (the checkpoint) and A_{s'+3} of the next segment wait in
+    // registers until the segment ends (their LDS slots are still read by this segment's products), A_{s'+2} and A_{s'+1} go straight to their slots.
+    float4 nh = seg_h(0), na = seg_a(0);   // H checkpoints are requested one segment ahead, A checkpoints two
+    int par = 0;
+    auto adj_products = [&](v2f aX, v2f aY, v2f (&tX)[3], v2f (&tY)[3]) {   // what a pixel sends to its eight neighbours (push form), summed per target row
+        const v2f aYs = swp2(aY);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const v2f M = mBX[d] * aX;                                   // (P_-(c0), P_+(c3)): what leaves for the neighbouring lanes
+            tX[d] = v2f{dpp_shr1(M[1]), dpp_shl1(M[0])};                 // (P_+(c3 of the lane before), P_-(c0 of the lane after))
+            tX[d] = __builtin_elementwise_fma(mBY[d], aY, tX[d]);        // + (P_-(c1), P_+(c2))
+            tY[d] = mAX[d] * aX;                                         // (P_+(c0), P_-(c3))
+            tY[d] = __builtin_elementwise_fma(mAYs[d], aYs, tY[d]);      // + (P_-(c2), P_+(c1))
+            if (d != 1) {
+                tX[d] = __builtin_elementwise_fma(n0X[d], aX, tX[d]);
+                tY[d] = __builtin_elementwise_fma(n0Y[d], aY, tY[d]);
+            }
+        }
+    };
+    auto segments = [&](auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        {   // the adjoint levels of segment 0: A_4 -> A_3, A_2, A_1, each parked in the thread's own LDS slot
+            const float4 aq4 = NSEG == 1 ? img_to_reg(na) : na;
+            v2f aX = v2f{aq4.x, aq4.y}, aY = v2f{aq4.z, aq4.w};
+            sA[CK - 1][tid] = aq4;
+#pragma unroll 1
+            for (int l = CK - 1; l >= 1; --l) {
+                v2f tX[3], tY[3];
+                adj_products(aX, aY, tX, tY);
+                sT[par][0][tid] = make_float4(tX[0][0], tX[0][1], tY[0][0], tY[0][1]);   // dy = +1: to the row below
+                sT[par][1][tid] = make_float4(tX[2][0], tX[2][1], tY[2][0], tY[2][1]);   // dy = -1: to the row above
+                lds_barrier();
+                const float4 fa = sT[par][0][tup_i], fb = sT[par][1][tdn_i];
+                par ^= 1;
+                aX = tX[1] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y};
+                aY = tY[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w};
+                if (MASKED && !inimg) { aX = zero2; aY = zero2; }
+                sA[l - 1][tid] = make_float4(aX[0], aX[1], aY[0], aY[1]);
+            }
+            if (NSEG > 1) na = seg_a(1);
+        }
+#pragma unroll 1
+        for (int j = 0; j < NSEG; ++j) {
+            // (the sweeps' planes are in register order already; blur / dL/dout are in image order)
+            float4 hq = j == 0 ? img_to_reg(nh) : nh;
+            const bool chain = j + 1 < NSEG;                                   // the next segment's adjoint levels are computed during this one
+            const float4 keep3 = chain ? (j + 1 == NSEG - 1 ? img_to_reg(na) : na) : z4;   // A_{s'+4}: the next segment's checkpoint
+            float4 keep2 = z4;                                                 // A_{s'+3}
+            if (j + 1 < NSEG) nh = seg_h(j + 1);
+            if (j + 2 < NSEG) na = seg_a(j + 2);
+            v2f aX = v2f{keep3.x, keep3.y}, aY = v2f{keep3.z, keep3.w};
+            sH[0][tid] = hq;
+            lds_barrier();
+            auto rows = [&](int l, v2f (&Xr)[3], v2f (&Yr)[3], v2f (&Dr)[3]) {   // rows y + 1, y, y - 1 of H_{s+l} (at the region's first / last row: the own row again, halo)
+                const float4 q[3] = {sH[l & 1][tdn_i], hq, sH[l & 1][tup_i]};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    Xr[d] = v2f{q[d].x, q[d].y};
+                    Yr[d] = v2f{q[d].z, q[d].w};
+                    Dr[d] = v2f{dpp_shr1(q[d].y), dpp_shl1(q[d].x)};   // (c3 of the lane before, c0 of the lane after; 0 at the region's edge: halo)
+                }
+            };
+            auto products = [&](int l, const v2f (&Xr)[3], const v2f (&Yr)[3], const v2f (&Dr)[3]) {   // dW' += A_{s+l+1} x the neighbours of H_{s+l}; dC += A_{s+l+1}
+                const float4 aq = sA[l][tid];
+                const v2f bX = v2f{aq.x, aq.y}, bY = v2f{aq.z, aq.w}, bYs = swp2(bY);
+                dCX += bX;
+                dCY += bY;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    dAX[d] = __builtin_elementwise_fma(bX, Yr[d], dAX[d]);
+                    dBX[d] = __builtin_elementwise_fma(bX, Dr[d], dBX[d]);
+                    dBY[d] = __builtin_elementwise_fma(bY, Xr[d], dBY[d]);
+                    dAYs[d] = __builtin_elementwise_fma(bYs, Yr[d], dAYs[d]);
+                    if (d != 1) {
+                        dN0X[d] = __builtin_elementwise_fma(bX, Xr[d], dN0X[d]);
+                        dN0Y[d] = __builtin_elementwise_fma(bY, Yr[d], dN0Y[d]);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int l = 0; l < CK - 1; ++l) {
+                v2f Xr[3], Yr[3], Dr[3];
+                rows(l, Xr, Yr, Dr);
+                if (wave_in_tile_rows) products(l, Xr, Yr, Dr);
+                // ONE basic block: the H step and an adjoint step of the next segment (of zeros in the last segment), for the scheduler to interleave
+                v2f tX[3], tY[3];
+                adj_products(aX, aY, tX, tY);
+                v2f nX = cpX, nY = cpY, nYs = mAYs[0] * Yr[0];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    nX = __builtin_elementwise_fma(mAX[d], Yr[d], nX);
+                    nX = __builtin_elementwise_fma(mBX[d], Dr[d], nX);
+                    nY = __builtin_elementwise_fma(mBY[d], Xr[d], nY);
+                    if (d != 0) nYs = __builtin_elementwise_fma(mAYs[d], Yr[d], nYs);
+                    if (d != 1) {
+                        nX = __builtin_elementwise_fma(n0X[d], Xr[d], nX);
+                        nY = __builtin_elementwise_fma(n0Y[d], Yr[d], nY);
+                    }
+                }
+                nY += swp2(nYs);
+                if (MASKED && !inimg) { nX = zero2; nY = zero2; }
+                hq = make_float4(nX[0], nX[1], nY[0], nY[1]);
+                sT[par][0][tid] = make_float4(tX[0][0], tX[0][1], tY[0][0], tY[0][1]);   // dy = +1: to the row below
+                sT[par][1][tid] = make_float4(tX[2][0], tX[2][1], tY[2][0], tY[2][1]);   // dy = -1: to the row above
+                sH[(l + 1) & 1][tid] = hq;   // (the plane read two steps ago: everybody is past the barrier in between)
+                lds_barrier();               // (one barrier for both exchanges)
+                const float4 fa = sT[par][0][tup_i], fb = sT[par][1][tdn_i];     // from the row above, sent down / from the row below, sent up
+                par ^= 1;
+                aX = tX[1] + v2f{fa.x, fa.y} + v2f{fb.x, fb.y};
+                aY = tY[1] + v2f{fa.z, fa.w} + v2f{fb.z, fb.w};
+                if (MASKED && !inimg) { aX = zero2; aY = zero2; }
+                const float4 an = make_float4(aX[0], aX[1], aY[0], aY[1]);     // A_{s'+3-l} of the next segment
+                if (l == 0) keep2 = an;                       // its slot (and the checkpoint's) is still read by this segment's products
+                else if (chain) sA[CK - 2 - l][tid] = an;     // l = 1 -> slot 1 (read above, in this iteration), l = 2 -> slot 0 (read at l = 0)
+            }
+            {
+                v2f Xr[3], Yr[3], Dr[3];
+                rows(CK - 1, Xr, Yr, Dr);
+                if (wave_in_tile_rows) products(CK - 1, Xr, Yr, Dr);
+            }
+            if (chain) { sA[CK - 1][tid] = keep3; sA[CK - 2][tid] = keep2; }   // (own slots, read by this thread only: no barrier)
+        }
+    };
+#endif
     const int ry0 = by * CK_TR - CK, xg0 = bx * CK_TG - 1;
     const bool blk_in = ry0 >= 0 && ry0 + CK_ROWS <= H && xg0 >= 0 && xg0 + CK_GR <= W4;
     if (blk_in) segments(std::false_type{});
