@@ -108,3 +108,14 @@ def test_dropin_module_name():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.Affinity_Propagate is cspn_amd.Affinity_Propagate
+
+
+def test_graft_entry_build_runs_and_checks_the_abi_version():
+    """what the driver runs as its build check (no GPU needed): compiles whatever is out of date, loads the library, compares its ABI version
+    with the binding's and the header's"""
+    import re
+    import __graft_entry__ as ge
+    from cspn_amd import _lib
+    ge.build()
+    hdr = open(os.path.join(ROOT, "include", "cspn_amd.h")).read()
+    assert int(re.search(r"#define CSPN_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == _lib.load().cspn_abi_version()
