@@ -82,6 +82,21 @@ def run(cases=40, seed=1, verbose=True):
               tol = 2e-5 * float(r_[fin].abs().max()) + 2e-4 * r_[fin].abs()
               assert bool(((a_[fin] - r_[fin]).abs() <= tol).all()), ("2D bwd", B, H, W, norm, sp, float((a_[fin] - r_[fin]).abs().max()))
           nb2 += 1
+          # round 6: the backward of the pre-normalised contract -- the gradient w.r.t. gate_wb (= w above) against torch autograd through the same loop
+          from tools.torch_path import _gather8
+          w0, h1 = wb.clone().requires_grad_(True), h.clone().requires_grad_(True)
+          gs_, m_, cur = w0.sum(1, keepdim=True), (s.sign() if s is not None else None), h1
+          for _ in range(N):
+              cur = (1.0 - gs_) * h1 + (w0 * _gather8(cur)).sum(1, keepdim=True)
+              if m_ is not None:
+                  cur = (1.0 - m_) * cur + m_ * h1
+          cur.backward(go)
+          gw, gh2 = cspn_amd.cspn2d_backward(wb, h, s, go, N, "prenorm")
+          for a_, r_ in ((gw, w0.grad), (gh2, h1.grad)):
+              fin = torch.isfinite(r_)
+              assert torch.equal(torch.isfinite(a_), fin), ("2D prenorm bwd finite", B, H, W, norm, sp)
+              tol = 2e-5 * float(r_[fin].abs().max()) + 2e-4 * r_[fin].abs()
+              assert bool(((a_[fin] - r_[fin]).abs() <= tol).all()), ("2D prenorm bwd", B, H, W, norm, sp, float((a_[fin] - r_[fin]).abs().max()))
       # ---- 3D
       B, D, H, W = rnd.randint(1, 3), rnd.randint(1, 40), rnd.randint(1, 70), 4 * rnd.randint(1, 60)
       N = rnd.randint(2, 14)
