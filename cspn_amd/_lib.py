@@ -91,6 +91,10 @@ def load():
     lib.cspn_guidance_head_workspace_bytes.argtypes = [c_int]
     lib.cspn_guidance_head_f32.restype = c_int
     lib.cspn_guidance_head_f32.argtypes = [vp] * 5 + [c_int] * 7 + [vp, c_size_t, vp]
+    lib.cspn_guidance_head_backward_workspace_bytes.restype = c_size_t
+    lib.cspn_guidance_head_backward_workspace_bytes.argtypes = [c_int] * 4
+    lib.cspn_guidance_head_backward_f32.restype = c_int
+    lib.cspn_guidance_head_backward_f32.argtypes = [vp] * 8 + [c_int] * 6 + [vp, c_size_t, vp]
     lib.cspn_unpool_backward_f32.restype = c_int
     lib.cspn_unpool_backward_f32.argtypes = [vp, vp, c_size_t, c_int, c_int, c_int, vp]
     lib.cspn_sparse_sample_workspace_bytes.restype = c_size_t

@@ -269,6 +269,22 @@ int cspn_guidance_head_f32(const float* x, const float* w_guidance, const float*
     return head_forward(x, w_guidance, w_blur, guidance_out, blur_out, B, C, h, w, H, W, mode, workspace, (hipStream_t)stream);
 }
 
+size_t cspn_guidance_head_backward_workspace_bytes(int B, int C, int h, int w) { return (B > 0 && C > 0 && h > 0 && w > 0) ? head_backward_workspace(B, C, h, w) : 0; }
+
+int cspn_guidance_head_backward_f32(const float* x, const float* w_guidance, const float* w_blur, const float* grad_guidance, const float* grad_blur,
+                                    float* grad_x, float* grad_w_guidance, float* grad_w_blur, int B, int C, int h, int w, int H, int W, void* workspace,
+                                    size_t workspace_bytes, cspn_stream_t stream) {
+    if (!x || !w_guidance || !grad_guidance || B < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) { set_error("bad argument"); return CSPN_E_BADARG; }
+    if ((w_blur != nullptr) != (grad_blur != nullptr)) { set_error("w_blur and grad_blur come together"); return CSPN_E_BADARG; }
+    if (grad_w_blur && !w_blur) { set_error("grad_w_blur without a blur head"); return CSPN_E_BADARG; }
+    if (H > 2 * h || W > 2 * w) { set_error("H x W = %d x %d exceeds the unpooled %d x %d", H, W, 2 * h, 2 * w); return CSPN_E_BADARG; }
+    if (B == 0 || (!grad_x && !grad_w_guidance && !grad_w_blur)) return 0;
+    const size_t need = head_backward_workspace(B, C, h, w);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255u) != 0) { set_error("workspace: need %zu bytes, 256-byte aligned", need); return CSPN_E_WORKSPACE; }
+    if ((long long)B * 8 * H * W >= (1ll << 40) || (long long)C * h * w >= (1ll << 31)) { set_error("tensor too large"); return CSPN_E_UNSUPPORTED; }
+    return head_backward(x, w_guidance, w_blur, grad_guidance, grad_blur, grad_x, grad_w_guidance, grad_w_blur, B, C, h, w, H, W, workspace, (hipStream_t)stream);
+}
+
 int cspn_unpool_backward_f32(const float* grad_out, float* grad_x, size_t NC, int H, int W, int stride, cspn_stream_t stream) {
     if (!grad_out || !grad_x || H <= 0 || W <= 0 || stride < 1) { set_error("bad argument"); return CSPN_E_BADARG; }
     const size_t n_in = NC * (size_t)H * W;

@@ -79,6 +79,9 @@ int backward3d(const float* g, const float* feat, const float* gout, float* gg, 
 // ---- the producer of the path's inputs (cspn_head.hip): Unpool + 3x3 conv C -> 8 (guidance) and C -> 1 (blur) as one kernel; mode 0 raw guidance,
 // 1 / 2 gate_wb of '8sum' / '8sum_abs' (the normalisation fused behind the conv) ----
 size_t head_workspace(int C);
+size_t head_backward_workspace(int B, int C, int h, int w);
+int head_backward(const float* x, const float* w6, const float* w5, const float* gg, const float* gb, float* dx, float* dw6, float* dw5, int B, int C, int h,
+                  int w, int H, int W, void* ws, hipStream_t st);
 int head_forward(const float* x, const float* w6, const float* w5, float* gout, float* bout, int B, int C, int h, int w, int H, int W, int mode,
                  void* ws, hipStream_t st);
 

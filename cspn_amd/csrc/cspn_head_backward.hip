@@ -1,0 +1,245 @@
+// cspn_head_backward.hip -- the gradient of the guidance heads of cspn_head.hip (reference cspn_pytorch/models/torch_resnet_cspn_nyu.py:187-206, Unpool :41-54;
+// what autograd computes when the training loop back-propagates through :372-373): raw mode only (the heads' own outputs; the chain through a normalising
+// epilogue is the PRENORM backward's, cspn2d_backward.hip).
+//     out[o][Y][X] = sum_{c,ky,kx} W[o][c][ky][kx] U[c][Y + ky - 1][X + kx - 1],   U[c][2i][2j] = x[c][i][j], zeros elsewhere / beyond the narrowed H x W
+//     dL/dx[c][i][j]      = sum_{o,ky,kx} W[o][c][ky][kx] g[o][2i + 1 - ky][2j + 1 - kx]                        (g = dL/dout, zero outside the output)
+//     dL/dW[o][c][ky][kx] = sum_{b,i,j}   x[b][c][i][j]   g[b][o][2i + 1 - ky][2j + 1 - kx]
+// Both are the forward's 81 products per (input pixel, channel) again: 61 GFLOP each at [64,64,152,608].
+//   * head_bwd_x_kernel: one lane = one input pixel; its 9 x 3 x 3 window of g (81 values) is loaded ONCE into registers (27 8-byte loads + the left column from the
+//     neighbouring lane by DPP), then every channel takes 41 packed FMAs over PAIRS of taps with the weights as scalar operands (the pair-of-channels form
+//     broadcasts g, and the compiler hoists the 81 broadcast pairs out of the channel loop: 168 registers).
+//   * head_bwd_w_kernel: a GEMM -- [81 taps] x [pixels] x [C channels], K = every input pixel of the batch -- on the matrix cores: v_mfma_f32_32x32x2_f32, taps
+//     padded to 96 (3 row blocks), channels in blocks of 32; a wave keeps all 3 x 2 accumulator blocks (96 registers) over its share of the pixels and writes them
+//     once; head_bwd_w_reduce_kernel sums the waves' partial sums in a fixed order (deterministic: no atomics).
+#include <cstdint>
+
+#include "cspn_common.h"
+
+namespace cspn {
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_shr1(float t) {   // the value of the lane before (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+
+// ---- dL/dx ----------------------------------------------------------------------------------------------------------------------------
+// weights of a channel in the order the kernel walks the window: wq[c][t = o * 9 + r * 3 + k] = W[o][c][2 - r][2 - k]  (r = window row: Y = 2i - 1 + r,
+// k = window column: X = 2j - 1 + k); o = 8: the blur head (zeros if absent); t = 81: 0 (the window is held as 41 register PAIRS of neighbouring taps)
+constexpr int XREC = 82;
+__global__ __launch_bounds__(256) void head_bwdx_pack_kernel(const float* __restrict__ w6, const float* __restrict__ w5, float* __restrict__ wq, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= C * XREC) return;
+    const int c = idx / XREC, t = idx - c * XREC;
+    const int o = t / 9, r = (t - o * 9) / 3, k = t - o * 9 - r * 3;
+    float v = 0.f;
+    if (t < 81) {
+        const int tap = (2 - r) * 3 + (2 - k);
+        v = o < 8 ? w6[((size_t)o * C + c) * 9 + tap] : (w5 ? w5[(size_t)c * 9 + tap] : 0.f);
+    }
+    wq[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ gg, const float* __restrict__ gb, const float* __restrict__ wq,
+                                                          float* __restrict__ dx, int C, int h, int w, int H, int W, int B) {
+    const int wq_ = (w + 62) / 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_xcd = gridDim.x >> 3;   // (a contiguous eighth of the units per XCD: neighbouring rows share a row of g)
+    const int unit = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wv;
+    const int seg = unit % wq_;
+    const int i = (unit / wq_) % h, b = unit / (wq_ * h);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int j = seg * 63 + lane - 1;                    // lane 0: the column before the segment (it only serves lane 1)
+    const size_t HWo = (size_t)H * W, hw = (size_t)h * w;
+    // the window G[t = o * 9 + r * 3 + k] = g[o][2i - 1 + r][2j - 1 + k] (zero outside the output) as pairs (G[2p], G[2p + 1]): a packed FMA takes two taps
+    f2 GP[41];
+    GP[40] = f2{0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float* src = o < 8 ? gg + ((size_t)b * 8 + o) * HWo : (gb ? gb + (size_t)b * HWo : nullptr);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int Y = 2 * i - 1 + r, X = 2 * j;
+            float a = 0.f, c = 0.f;
+            if (src && Y >= 0 && Y < H && j >= 0) {
+                const float* p = src + (size_t)Y * W + X;
+                if (X + 1 < W) { f2 v; __builtin_memcpy(&v, p, 8); a = v.x; c = v.y; }
+                else if (X < W) a = p[0];
+            }
+            const float l = wave_shr1(c);                 // column 2j - 1 = the lane before's 2(j - 1) + 1
+            const int t = o * 9 + r * 3;
+            GP[t >> 1][t & 1] = l;
+            GP[(t + 1) >> 1][(t + 1) & 1] = a;
+            GP[(t + 2) >> 1][(t + 2) & 1] = c;
+        }
+    }
+    const bool own = lane >= 1 && j < w;
+    const bool fed = own && 2 * i < H && 2 * j < W;       // (an input whose unpooled position lies beyond the narrowed output fed nothing: gradient 0)
+    float* dst = dx + (size_t)b * C * hw + (size_t)i * w + (own ? j : 0);
+    for (int c = 0; c < C; ++c) {
+        const f2* wc = reinterpret_cast<const f2*>(wq + (size_t)c * XREC);   // scalar loads: 82 dwords per channel
+        f2 acc = wc[0] * GP[0], acd = wc[1] * GP[1];      // (two chains)
+#pragma unroll
+        for (int p = 2; p < 41; p += 2) {
+            acc = __builtin_elementwise_fma(wc[p], GP[p], acc);
+            if (p + 1 < 41) acd = __builtin_elementwise_fma(wc[p + 1], GP[p + 1], acd);
+        }
+        acc += acd;
+        if (own) dst[(size_t)c * hw] = fed ? acc.x + acc.y : 0.f;
+    }
+}
+
+// ---- dL/dW ----------------------------------------------------------------------------------------------------------------------------
+// D[tap][channel] += sum over pixels A[tap][pixel] B[pixel][channel], A = the window value g[o][2i - 1 + r][2j - 1 + k] (tap t = o * 9 + r * 3 + k, padded to 96),
+// B = x[channel][i][j].  v_mfma_f32_32x32x2_f32: A 32 x 2 (lane l: row l % 32, k = l / 32), B 2 x 32 (lane l: k = l / 32, column l % 32), D 32 x 32 in 16
+// registers (lane l: column l % 32; register q: row (q / 4) * 8 + (l / 32) * 4 + q % 4).  A tile = 8 consecutive pixels of an input row: lanes 0-31 take
+// pixels j0 .. j0 + 3, lanes 32-63 pixels j0 + 4 .. j0 + 7, four MFMA steps per (tap block, channel block) -- a lane reads its tap's four window values as 8
+// consecutive floats (stride 2 between pixels) and its channel's four pixels as 16 bytes; the next tile's reads are issued before the current tile's MFMAs.
+constexpr int DW_TILE = 8;
+struct DwTile { float a[3][4]; float bq[2][4]; };
+
+template <int NB>
+__device__ __forceinline__ void dw_load(DwTile& T, const float* __restrict__ x, const float* __restrict__ gg, const float* __restrict__ gb, long long tile, int tiles_w,
+                                        int hfed, int C, int c0, int h, int w, int H, int W, int lane) {
+    const int tw = (int)(tile % tiles_w);
+    const int i = (int)((tile / tiles_w) % hfed), b = (int)(tile / ((long long)tiles_w * hfed));
+    const int half = lane >> 5, id = lane & 31;
+    const int jb = tw * DW_TILE + 4 * half;                     // this lane's first pixel
+    const size_t HWo = (size_t)H * W, hw = (size_t)h * w;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int t = tb * 32 + id;
+        const int o = t / 9, r = (t - o * 9) / 3, k = t - o * 9 - r * 3;
+        const float* src = t >= 81 ? nullptr : (o < 8 ? gg + ((size_t)b * 8 + o) * HWo : (gb ? gb + (size_t)b * HWo : nullptr));
+        const int Y = 2 * i - 1 + r, Xb = 2 * jb - 1 + k;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (src && Y >= 0 && Y < H) {
+            const float* p = src + (size_t)Y * W;
+            if (Xb >= 0 && Xb + 7 < W) {                         // 8 consecutive floats, every other one is a pixel's
+                float q[8];
+                __builtin_memcpy(q, p + Xb, 32);
+                v[0] = q[0]; v[1] = q[2]; v[2] = q[4]; v[3] = q[6];
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) { const int X = Xb + 2 * s_; if (X >= 0 && X < W) v[s_] = p[X]; }
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) T.a[tb][s_] = v[s_];
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ch = c0 + nb * 32 + id;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ch < C) {
+            const float* p = x + ((size_t)b * C + ch) * hw + (size_t)i * w;
+            if (jb + 3 < w && 2 * (jb + 3) < W) __builtin_memcpy(v, p + jb, 16);
+            else {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) { const int j = jb + s_; if (j < w && 2 * j < W) v[s_] = p[j]; }   // (beyond the narrowed output: fed nothing)
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) T.bq[nb][s_] = v[s_];
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ gg, const float* __restrict__ gb,
+                                                             float* __restrict__ part, int C, int c0, int h, int w, int H, int W, long long tiles, int tiles_w,
+                                                             int hfed, int nwave) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave >= nwave) return;
+    const long long t0 = tiles * wave / nwave, t1 = tiles * (wave + 1) / nwave;   // this wave's share of the tiles
+    f16v acc[3][NB];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[tb][nb][q] = 0.f;
+    DwTile nxt;
+    if (t0 < t1) dw_load<NB>(nxt, x, gg, gb, t0, tiles_w, hfed, C, c0, h, w, H, W, lane);
+    for (long long t = t0; t < t1; ++t) {
+        const DwTile cur = nxt;
+        if (t + 1 < t1) dw_load<NB>(nxt, x, gg, gb, t + 1, tiles_w, hfed, C, c0, h, w, H, W, lane);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[tb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tb][s_], cur.bq[nb][s_], acc[tb][nb], 0, 0, 0);
+    }
+    float* dst = part + (size_t)wave * 3 * NB * 16 * 64 + lane;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dst[((tb * NB + nb) * 16 + q) * 64] = acc[tb][nb][q];
+}
+
+// dW[o][c][ky][kx] = sum over the waves' partial blocks, in wave order (deterministic)
+__global__ __launch_bounds__(256) void head_bwd_w_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw6, float* __restrict__ dw5, int C, int c0,
+                                                                 int NB, int nwave) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nch = NB * 32;
+    if (idx >= 81 * nch) return;
+    const int t = idx / nch, cl = idx - t * nch, ch = c0 + cl;
+    if (ch >= C) return;
+    const int tb = t >> 5, i = t & 31, nb = cl >> 5, jc = cl & 31;
+    const int q = (i >> 3) * 4 + (i & 3), l = ((i & 7) >> 2) * 32 + jc;
+    const float* p = part + ((size_t)(tb * NB + nb) * 16 + q) * 64 + l;
+    const size_t stride = (size_t)3 * NB * 16 * 64;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int wv = 0;
+    for (; wv + 3 < nwave; wv += 4) { s0 += p[(size_t)wv * stride]; s1 += p[(size_t)(wv + 1) * stride]; s2 += p[(size_t)(wv + 2) * stride]; s3 += p[(size_t)(wv + 3) * stride]; }
+    for (; wv < nwave; ++wv) s0 += p[(size_t)wv * stride];
+    const float v = (s0 + s1) + (s2 + s3);
+    const int o = t / 9, r = (t - o * 9) / 3, k = t - o * 9 - r * 3;
+    const int tap = (2 - r) * 3 + (2 - k);
+    if (o < 8) { if (dw6) dw6[((size_t)o * C + ch) * 9 + tap] = v; }
+    else if (dw5) dw5[(size_t)ch * 9 + tap] = v;
+}
+
+}  // namespace
+
+constexpr int DW_MAX_WAVES = 2048;
+static size_t bwdx_bytes(int C) { return (((size_t)C * XREC * sizeof(float)) + 255) & ~(size_t)255; }
+size_t head_backward_workspace(int B, int C, int h, int w) {
+    (void)B; (void)C; (void)h; (void)w;
+    return bwdx_bytes(C) + (size_t)DW_MAX_WAVES * 3 * 2 * 16 * 64 * sizeof(float);   // + the waves' partial blocks of dL/dW (64 channels at a time)
+}
+
+int head_backward(const float* x, const float* w6, const float* w5, const float* gg, const float* gb, float* dx, float* dw6, float* dw5, int B, int C, int h,
+                  int w, int H, int W, void* ws, hipStream_t st) {
+    if (dx) {
+        float* wq = (float*)ws;
+        hipLaunchKernelGGL(head_bwdx_pack_kernel, dim3((C * XREC + 255) / 256), dim3(256), 0, st, w6, w5, wq, C);
+        const long long units = (long long)B * h * ((w + 62) / 63);
+        const long long groups = ((units + 3) / 4 + 7) / 8 * 8;
+        hipLaunchKernelGGL(head_bwd_x_kernel, dim3((unsigned)groups), dim3(256), 0, st, gg, gb, wq, dx, C, h, w, H, W, B);
+        if (int e = check_launch("head_bwd_x_kernel")) return e;
+    }
+    if (dw6 || dw5) {
+        float* part = (float*)((char*)ws + bwdx_bytes(C));
+        const int hfed = (H + 1) / 2 < h ? (H + 1) / 2 : h;     // input rows whose unpooled row lies inside the (narrowed) output
+        const int wfed = (W + 1) / 2 < w ? (W + 1) / 2 : w;
+        const int tiles_w = (wfed + DW_TILE - 1) / DW_TILE;
+        const long long tiles = (long long)B * hfed * tiles_w;
+        const int nwave = (int)(tiles < DW_MAX_WAVES ? tiles : DW_MAX_WAVES);
+        for (int c0 = 0; c0 < C; c0 += 64) {                     // 64 channels at a time (two column blocks of the matrix core)
+            const int NB = C - c0 > 32 ? 2 : 1;
+            if (NB == 2) hipLaunchKernelGGL(head_bwd_w_kernel<2>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+            else hipLaunchKernelGGL(head_bwd_w_kernel<1>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+            hipLaunchKernelGGL(head_bwd_w_reduce_kernel, dim3((81 * NB * 32 + 255) / 256), dim3(256), 0, st, part, dw6, dw5, C, c0, NB, nwave);
+        }
+        if (int e = check_launch("head_bwd_w_kernel")) return e;
+    }
+    return 0;
+}
+
+}  // namespace cspn

@@ -141,25 +141,11 @@ def createSparseDepthImage(depth_image, n_sample, mode="nyu", seed=0):
     return out
 
 
-def guidance_heads(x, weight_guidance, weight_blur=None, oheight=0, owidth=0, norm_type=None):
-    """The producer of the propagation's inputs (SURVEY.md 8f-2): what the reference computes as
-        guidance = self.gud_up_proj_layer6(x); x = self.gud_up_proj_layer5(x)          (torch_resnet_cspn_nyu.py:372-373)
-    with both heads Simple_Gudi_UpConv_Block_Last_Layer (:187-206: Unpool + narrow to (oheight, owidth) + bias-free 3x3 conv), in ONE kernel that never
-    multiplies the structurally zero taps.  x [B,C,h,w]; weight_guidance = layer6.conv1.weight [8,C,3,3]; weight_blur = layer5.conv1.weight [1,C,3,3] or None.
-    norm_type None: -> (guidance [B,8,H,W], blur [B,1,H,W] | None), bit-compatible inputs of Affinity_Propagate(..., norm_type)(guidance, blur, sparse).
-    norm_type '8sum' | '8sum_abs': the guidance comes back normalised -- gate_wb of affinity_normalization (cspn.py:85-144) -- for
-    cspn2d_forward(gate_wb, blur, sparse, n_iter, 'prenorm') / cspn_amd.propagate_prenorm.  The head itself is forward only (inference / the frozen-head case)."""
+def _heads_forward(xx, wg, wb, H, W, norm):
     lib = _lib.load()
-    xx = _prep(x, "x")
     B, C, h, w = xx.shape
-    wg = _prep(weight_guidance, "weight_guidance", (8, C, 3, 3))
-    wb = _prep(weight_blur, "weight_blur", (1, C, 3, 3)) if weight_blur is not None else None
-    H, W = (int(oheight), int(owidth)) if (oheight and owidth) else (2 * h, 2 * w)
     g = torch.empty(B, 8, H, W, dtype=torch.float32, device=xx.device)
     b = torch.empty(B, 1, H, W, dtype=torch.float32, device=xx.device) if wb is not None else None
-    norm = _lib.NORM_TYPES["none" if norm_type is None else norm_type]
-    if norm_type not in (None, "8sum", "8sum_abs"):
-        raise ValueError("norm_type must be None (raw guidance), '8sum' or '8sum_abs' (gate_wb)")
     with torch.cuda.device(xx.device):
         wsb = lib.cspn_guidance_head_workspace_bytes(C)
         ws = _workspace(wsb, xx.device)
@@ -168,3 +154,68 @@ def guidance_heads(x, weight_guidance, weight_blur=None, oheight=0, owidth=0, no
                                         torch.cuda.current_stream(xx.device).cuda_stream)
     _lib.check(rc, "cspn_guidance_head_f32")
     return g, b
+
+
+def guidance_heads_backward(x, weight_guidance, weight_blur, grad_guidance, grad_blur, need_x=True, need_w=True):
+    """cspn_guidance_head_backward_f32: (dL/dx, dL/dweight_guidance, dL/dweight_blur) of the RAW heads -- what torch autograd computes through the two reference
+    layers (torch_resnet_cspn_nyu.py:187-206) -- from dL/dguidance [B,8,H,W] and dL/dblur [B,1,H,W] (None without a blur head); skipped outputs are None."""
+    lib = _lib.load()
+    xx = _prep(x, "x")
+    B, C, h, w = xx.shape
+    wg = _prep(weight_guidance, "weight_guidance", (8, C, 3, 3))
+    wb = _prep(weight_blur, "weight_blur", (1, C, 3, 3)) if weight_blur is not None else None
+    H, W = int(grad_guidance.shape[2]), int(grad_guidance.shape[3])
+    gg = _prep(grad_guidance, "grad_guidance", (B, 8, H, W))
+    gb = _prep(grad_blur, "grad_blur", (B, 1, H, W)) if wb is not None else None
+    dx = torch.empty_like(xx) if need_x else None
+    dwg = torch.empty_like(wg) if need_w else None
+    dwb = torch.empty_like(wb) if (need_w and wb is not None) else None
+    with torch.cuda.device(xx.device):
+        wsb = lib.cspn_guidance_head_backward_workspace_bytes(B, C, h, w)
+        ws = _workspace(wsb, xx.device)
+        rc = lib.cspn_guidance_head_backward_f32(xx.data_ptr(), wg.data_ptr(), wb.data_ptr() if wb is not None else None, gg.data_ptr(),
+                                                 gb.data_ptr() if gb is not None else None, dx.data_ptr() if dx is not None else None,
+                                                 dwg.data_ptr() if dwg is not None else None, dwb.data_ptr() if dwb is not None else None,
+                                                 B, C, h, w, H, W, ws.data_ptr(), wsb, torch.cuda.current_stream(xx.device).cuda_stream)
+    _lib.check(rc, "cspn_guidance_head_backward_f32")
+    return dx, dwg, dwb
+
+
+class _GuidanceHeadsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wg, wb, H, W):
+        ctx.save_for_backward(x, wg, wb)
+        g, b = _heads_forward(x, wg, wb, H, W, _lib.NORM_TYPES["none"])
+        return g, b
+
+    @staticmethod
+    def backward(ctx, grad_g, grad_b):
+        x, wg, wb = ctx.saved_tensors
+        if grad_g is None:
+            grad_g = torch.zeros(x.shape[0], 8, *((grad_b.shape[2:]) if grad_b is not None else (2 * x.shape[2], 2 * x.shape[3])), device=x.device)
+        if wb is not None and grad_b is None:
+            grad_b = torch.zeros(x.shape[0], 1, grad_g.shape[2], grad_g.shape[3], device=x.device)
+        dx, dwg, dwb = guidance_heads_backward(x, wg, wb, grad_g.contiguous(), grad_b.contiguous() if grad_b is not None else None,
+                                               need_x=ctx.needs_input_grad[0], need_w=ctx.needs_input_grad[1] or (wb is not None and ctx.needs_input_grad[2]))
+        return dx, dwg if ctx.needs_input_grad[1] else None, dwb if (wb is not None and ctx.needs_input_grad[2]) else None, None, None
+
+
+def guidance_heads(x, weight_guidance, weight_blur=None, oheight=0, owidth=0, norm_type=None):
+    """The producer of the propagation's inputs (SURVEY.md 8f-2): what the reference computes as
+        guidance = self.gud_up_proj_layer6(x); x = self.gud_up_proj_layer5(x)          (torch_resnet_cspn_nyu.py:372-373)
+    with both heads Simple_Gudi_UpConv_Block_Last_Layer (:187-206: Unpool + narrow to (oheight, owidth) + bias-free 3x3 conv), in ONE kernel that never
+    multiplies the structurally zero taps.  x [B,C,h,w]; weight_guidance = layer6.conv1.weight [8,C,3,3]; weight_blur = layer5.conv1.weight [1,C,3,3] or None.
+    norm_type None: -> (guidance [B,8,H,W], blur [B,1,H,W] | None), bit-compatible inputs of Affinity_Propagate(..., norm_type)(guidance, blur, sparse);
+    differentiable w.r.t. x and both weights (cspn_guidance_head_backward_f32: the gradients torch autograd computes through the reference layers).
+    norm_type '8sum' | '8sum_abs': the guidance comes back normalised -- gate_wb of affinity_normalization (cspn.py:85-144) -- for
+    cspn2d_forward(gate_wb, blur, sparse, n_iter, 'prenorm') / cspn_amd.propagate_prenorm; these two modes are forward only (inference / frozen heads)."""
+    xx = _prep(x, "x")
+    B, C, h, w = xx.shape
+    wg = _prep(weight_guidance, "weight_guidance", (8, C, 3, 3))
+    wb = _prep(weight_blur, "weight_blur", (1, C, 3, 3)) if weight_blur is not None else None
+    H, W = (int(oheight), int(owidth)) if (oheight and owidth) else (2 * h, 2 * w)
+    if norm_type not in (None, "8sum", "8sum_abs"):
+        raise ValueError("norm_type must be None (raw guidance), '8sum' or '8sum_abs' (gate_wb)")
+    if norm_type is None and torch.is_grad_enabled() and (xx.requires_grad or wg.requires_grad or (wb is not None and wb.requires_grad)):
+        return _GuidanceHeadsFunction.apply(xx, wg, wb, H, W)
+    return _heads_forward(xx, wg, wb, H, W, _lib.NORM_TYPES["none" if norm_type is None else norm_type])

@@ -44,7 +44,7 @@ extern "C" {
                               * 4: CSPN_NORM_PRENORM, cspn2d_normalize_f32, cspn2d_forward_prenorm_f32, cspn3d_backward_multi_f32; the
                               *    sited8 experiment's three entry points left the ABI (hook library, experiment builds); CSPN_ALGO_FUSED_PADDED
                               *    (what AUTO returns for W % 4 != 0; cspn2d_workspace_bytes grows accordingly for such widths);
-                              * 5: cspn_guidance_head_f32 (the producer of the path's inputs); CSPN_NORM_PRENORM on the 2D backward entry points */
+                              * 5: cspn_guidance_head_f32 (the producer of the path's inputs) and cspn_guidance_head_backward_f32; CSPN_NORM_PRENORM on the 2D backward entry points */
 
 /* hipStream_t, spelled without the HIP headers. NULL = the null stream. */
 typedef void* cspn_stream_t;
@@ -240,11 +240,22 @@ int cspn_sparse_sample_f32(const float* depth, float* sparse_out, size_t n_image
  *   norm_type CSPN_NORM_NONE: guidance_out = the raw guidance, what gud_up_proj_layer6 returns (feed it to cspn2d_forward_f32 with '8sum' / '8sum_abs');
  *   CSPN_NORM_8SUM / CSPN_NORM_8SUM_ABS: guidance_out = gate_wb = affinity_normalization (cspn.py:85-144) of that guidance, fused behind the conv (IEEE
  *   division: 0 / 0 = NaN as in the reference) -- the input contract of cspn2d_forward_f32 with CSPN_NORM_PRENORM; no stand-alone normalisation pass.
- * workspace: cspn_guidance_head_workspace_bytes(C) (the packed weights).  Forward only. */
+ * workspace: cspn_guidance_head_workspace_bytes(C) (the packed weights). */
 size_t cspn_guidance_head_workspace_bytes(int C);
 int cspn_guidance_head_f32(const float* x, const float* w_guidance, const float* w_blur, float* guidance_out, float* blur_out,
                            int B, int C, int h, int w, int H, int W, int norm_type,
                            void* workspace, size_t workspace_bytes, cspn_stream_t stream);
+
+/* The gradient of the raw heads (norm_type NONE above): what torch autograd computes through the two reference layers when the training loop back-propagates
+ * through torch_resnet_cspn_nyu.py:372-373.  grad_guidance [B,8,H,W] and grad_blur [B,1,H,W] (with w_blur; both or neither) are dL/d(outputs);
+ *   grad_x          [B,C,h,w]   dL/dx = sum_{o,ky,kx} W[o][c][ky][kx] g[o][2i + 1 - ky][2j + 1 - kx]   (inputs beyond the narrowed output: 0), or NULL to skip
+ *   grad_w_guidance [8,C,3,3], grad_w_blur [1,C,3,3]   dL/dW = sum over the batch and all input pixels of x g -- on the matrix cores (fp32 MFMA), the waves'
+ *                   partial sums added in a fixed order: deterministic; either or both may be NULL
+ * workspace: cspn_guidance_head_backward_workspace_bytes(B, C, h, w) bytes, 256-byte aligned. */
+size_t cspn_guidance_head_backward_workspace_bytes(int B, int C, int h, int w);
+int cspn_guidance_head_backward_f32(const float* x, const float* w_guidance, const float* w_blur, const float* grad_guidance, const float* grad_blur,
+                                    float* grad_x, float* grad_w_guidance, float* grad_w_blur, int B, int C, int h, int w, int H, int W,
+                                    void* workspace, size_t workspace_bytes, cspn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,36 @@ def guidance_head_oracle(x, w_guidance, w_blur=None, oheight=0, owidth=0):
                 out += np.einsum("oc,bcyx->boyx", wt[:, :, ky, kx], Up[:, :, ky:ky + H, kx:kx + W])
         return out.astype(np.float32)
     return conv(w_guidance), (conv(w_blur) if w_blur is not None else None)
+
+
+def guidance_head_backward_oracle(x, w_guidance, w_blur, grad_guidance, grad_blur=None, oheight=0, owidth=0):
+    """The gradient of guidance_head_oracle's two outputs (reference torch_resnet_cspn_nyu.py:187-206, back-propagated through at :372-373), numpy, fp64:
+        out[o][Y][X] = sum_{c,ky,kx} W[o][c][ky][kx] U[c][Y + ky - 1][X + kx - 1],  U[c][2i][2j] = x[c][i][j]  (zeros elsewhere / beyond the narrowed size)
+        dL/dx[c][i][j]       = sum_{o,ky,kx} W[o][c][ky][kx] g[o][2i + 1 - ky][2j + 1 - kx]
+        dL/dW[o][c][ky][kx]  = sum_{b,i,j}   x[b][c][i][j]   g[b][o][2i + 1 - ky][2j + 1 - kx]              (g = dL/dout, zero outside the output)
+    -> (dL/dx [B,C,h,w], dL/dw_guidance [8,C,3,3], dL/dw_blur [1,C,3,3] or None), float32.  Pinned to the unmodified reference's autograd by
+    tests/golden/head_grad_golden.npz."""
+    x = np.asarray(_f32(x), np.float64)
+    B, C, h, w = x.shape
+    H, W = (int(oheight), int(owidth)) if (oheight and owidth) else (2 * h, 2 * w)
+    planes = [(np.asarray(w_guidance, np.float64), np.asarray(grad_guidance, np.float64))]
+    if w_blur is not None and grad_blur is not None:
+        planes.append((np.asarray(w_blur, np.float64), np.asarray(grad_blur, np.float64)))
+    dx = np.zeros_like(x)
+    dws = []
+    for wt, g in planes:
+        O = wt.shape[0]
+        gp = np.zeros((B, O, 2 * h + 2, 2 * w + 2), np.float64)          # g[Y][X] at gp[Y + 1][X + 1]; zeros outside the (narrowed) output
+        gp[:, :, 1:H + 1, 1:W + 1] = g
+        dw = np.zeros_like(wt)
+        for ky in range(3):
+            for kx in range(3):
+                # Y = 2i + 1 - ky -> index 2i + 2 - ky; inputs whose unpooled position lies beyond the narrowed size feed nothing
+                win = gp[:, :, 2 - ky:2 - ky + 2 * h:2, 2 - kx:2 - kx + 2 * w:2]      # [B,O,h,w]
+                ok = np.zeros((h, w), bool)
+                ok[:(H + 1) // 2, :(W + 1) // 2] = True
+                win = win * ok
+                dx += np.einsum("oc,boyx->bcyx", wt[:, :, ky, kx], win)
+                dw[:, :, ky, kx] = np.einsum("bcyx,boyx->oc", x, win)
+        dws.append(dw.astype(np.float32))
+    return dx.astype(np.float32), dws[0], (dws[1] if len(dws) > 1 else None)

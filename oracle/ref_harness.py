@@ -117,3 +117,28 @@ def reference_guidance_heads(x, w_guidance, w_blur, oheight=0, owidth=0):
                 return l6(x), l5(x)
     finally:
         sys.path.remove(d)
+
+
+def reference_guidance_heads_grads(x, w_guidance, w_blur, grad_guidance, grad_blur, oheight=0, owidth=0):
+    """-> (dL/dx, dL/dw_guidance, dL/dw_blur) of L = sum(guidance * grad_guidance) + sum(blur * grad_blur) by torch autograd through the UNMODIFIED
+    reference heads (torch_resnet_cspn_nyu.py:187-206, Unpool :41-54): what back-propagating through :372-373 gives the backbone and the two convs."""
+    import sys
+    d = os.path.dirname(REF_MODEL)
+    sys.path.insert(0, d)
+    try:
+        with cuda_is_identity():
+            spec = importlib.util.spec_from_file_location("_reference_resnet_cspn", REF_MODEL)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            C = x.shape[1]
+            l6 = mod.Simple_Gudi_UpConv_Block_Last_Layer(C, 8, oheight, owidth)
+            l5 = mod.Simple_Gudi_UpConv_Block_Last_Layer(C, 1, oheight, owidth)
+            with torch.no_grad():
+                l6.conv1.weight.copy_(w_guidance)
+                l5.conv1.weight.copy_(w_blur)
+            xr = x.clone().requires_grad_(True)
+            g, b = l6(xr), l5(xr)
+            (g * grad_guidance).sum().add((b * grad_blur).sum()).backward()
+            return xr.grad.detach(), l6.conv1.weight.grad.detach(), l5.conv1.weight.grad.detach()
+    finally:
+        sys.path.remove(d)

@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import guidance_head_oracle, cspn2d_gate_wb_oracle, cspn2d_oracle  # noqa: E402
+from oracle import guidance_head_oracle, guidance_head_backward_oracle, cspn2d_gate_wb_oracle, cspn2d_oracle  # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
 NAMES = sorted({k.split("/")[0] for k in GOLD.files})
@@ -164,3 +164,104 @@ def test_head_fuzzed_shapes_vs_oracle():
             assert torch.equal(blur2, blur), what
             assert torch.equal(torch.isnan(wb), torch.isnan(ref)), what
             assert float((wb - ref).abs().nan_to_num().max()) <= 2e-5, what     # (weights are <= 1 in magnitude)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the heads' gradient (round 6)
+def _grad_golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "head_grad_golden.npz"))
+    for n in sorted({k.split("/")[0] for k in z.files}):
+        yield n, {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")}
+
+
+def test_head_backward_oracle_vs_reference_autograd_golden():
+    """oracle/oracle.py guidance_head_backward_oracle against the gradients the unmodified reference layers' autograd produced
+    (tests/golden/make_head_grad_golden.py)"""
+    n = 0
+    for name, c in _grad_golden():
+        oh, ow = (int(v) for v in c["meta"])
+        dx, d6, d5 = guidance_head_backward_oracle(c["x"], c["w6"], c["w5"], c["grad_guidance"], c["grad_blur"], oh, ow)
+        assert _rel(dx, c["grad_x"]) <= 1e-5 and _rel(d6, c["grad_w6"]) <= 1e-5 and _rel(d5, c["grad_w5"]) <= 1e-5, name
+        n += 1
+    assert n == 6
+
+
+def test_head_backward_oracle_vs_live_reference():
+    from oracle import ref_harness
+    if not ref_harness.available():
+        pytest.skip("reference tree not present")
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 6, 5, 7, generator=gen)
+    w6 = torch.randn(8, 6, 3, 3, generator=gen)
+    w5 = torch.randn(1, 6, 3, 3, generator=gen)
+    gg, gb = torch.randn(2, 8, 9, 13, generator=gen), torch.randn(2, 1, 9, 13, generator=gen)
+    rdx, rd6, rd5 = ref_harness.reference_guidance_heads_grads(x, w6, w5, gg, gb, 9, 13)
+    dx, d6, d5 = guidance_head_backward_oracle(x.numpy(), w6.numpy(), w5.numpy(), gg.numpy(), gb.numpy(), 9, 13)
+    assert _rel(dx, rdx.numpy()) <= 1e-5 and _rel(d6, rd6.numpy()) <= 1e-5 and _rel(d5, rd5.numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_head_backward_kernels_vs_reference_autograd_golden():
+    from cspn_amd.train_utils import guidance_heads_backward
+    for name, c in _grad_golden():
+        t = {k: _dev(v) for k, v in c.items() if k != "meta"}
+        dx, d6, d5 = guidance_heads_backward(t["x"], t["w6"], t["w5"], t["grad_guidance"], t["grad_blur"])
+        torch.cuda.synchronize()
+        assert _rel(dx.cpu().numpy(), c["grad_x"]) <= 1e-5, name
+        assert _rel(d6.cpu().numpy(), c["grad_w6"]) <= 2e-5 and _rel(d5.cpu().numpy(), c["grad_w5"]) <= 2e-5, name
+        # guidance head only; one of the two results only
+        dx2, d62, none = guidance_heads_backward(t["x"], t["w6"], None, t["grad_guidance"], None)
+        r = guidance_head_backward_oracle(c["x"], c["w6"], None, c["grad_guidance"], None, *(int(v) for v in c["meta"]))
+        assert none is None and _rel(dx2.cpu().numpy(), r[0]) <= 1e-5 and _rel(d62.cpu().numpy(), r[1]) <= 2e-5, name
+        dx3, a, b_ = guidance_heads_backward(t["x"], t["w6"], t["w5"], t["grad_guidance"], t["grad_blur"], need_w=False)
+        assert a is None and b_ is None and torch.equal(dx3, dx)
+        n_, d63, d53 = guidance_heads_backward(t["x"], t["w6"], t["w5"], t["grad_guidance"], t["grad_blur"], need_x=False)
+        assert n_ is None and torch.equal(d63, d6) and torch.equal(d53, d5)       # (deterministic: the partial sums are added in a fixed order)
+
+
+@pytest.mark.gpu
+def test_head_backward_fuzzed_shapes_and_autograd():
+    """40 seeded random shapes against the numpy oracle (channel counts around the matrix core's 32-column blocks, widths around the 8-pixel tiles and the
+    63-column segments, narrowed and odd outputs), and the autograd Function: guidance_heads(...) -> loss.backward() == the same through torch's conv"""
+    import torch.nn.functional as F
+    from cspn_amd.train_utils import guidance_heads, guidance_heads_backward
+    rng = np.random.default_rng(606)
+    for case in range(40):
+        B, C = int(rng.integers(1, 4)), int(rng.choice([1, 3, 31, 32, 33, 64, 65, 96]))
+        h = int(rng.integers(1, 12))
+        w = int(rng.choice([1, 3, 7, 8, 9, 62, 63, 64, 100]))
+        oh, ow = 0, 0
+        if rng.random() < 0.5:
+            oh, ow = int(rng.integers(max(1, 2 * h - 3), 2 * h + 1)), int(rng.integers(max(1, 2 * w - 3), 2 * w + 1))
+        H, W = (oh, ow) if oh else (2 * h, 2 * w)
+        gen = torch.Generator().manual_seed(1000 + case)
+        x = torch.randn(B, C, h, w, generator=gen)
+        w6 = torch.randn(8, C, 3, 3, generator=gen) / 3
+        w5 = torch.randn(1, C, 3, 3, generator=gen) / 3
+        gg, gb = torch.randn(B, 8, H, W, generator=gen), torch.randn(B, 1, H, W, generator=gen)
+        rdx, rd6, rd5 = guidance_head_backward_oracle(x.numpy(), w6.numpy(), w5.numpy(), gg.numpy(), gb.numpy(), oh, ow)
+        dx, d6, d5 = guidance_heads_backward(x.cuda(), w6.cuda(), w5.cuda(), gg.cuda(), gb.cuda())
+        what = "case %d: B%d C%d h%d w%d -> %dx%d" % (case, B, C, h, w, H, W)
+        assert _rel(dx.cpu().numpy(), rdx) <= 1e-5, what
+        assert _rel(d6.cpu().numpy(), rd6) <= 2e-5 and _rel(d5.cpu().numpy(), rd5) <= 2e-5, what
+    # through autograd, against torch's own conv on the unpooled map
+    B, C, h, w, oh, ow = 2, 64, 9, 70, 17, 139
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, C, h, w, generator=gen, device="cuda")
+    w6 = torch.randn(8, C, 3, 3, generator=gen, device="cuda") / 24
+    w5 = torch.randn(1, C, 3, 3, generator=gen, device="cuda") / 24
+    gg, gb = torch.randn(B, 8, oh, ow, generator=gen, device="cuda"), torch.randn(B, 1, oh, ow, generator=gen, device="cuda")
+    xa, w6a, w5a = (t.clone().requires_grad_(True) for t in (x, w6, w5))
+    g, b = guidance_heads(xa, w6a, w5a, oh, ow)
+    ((g * gg).sum() + (b * gb).sum()).backward()
+    xb, w6b, w5b = (t.double().clone().requires_grad_(True) for t in (x, w6, w5))
+    up = torch.zeros(C, 1, 2, 2, device="cuda", dtype=torch.float64)
+    up[:, :, 0, 0] = 1
+    U = F.conv_transpose2d(xb, up, stride=2, groups=C)[:, :, :oh, :ow]
+    ((F.conv2d(U, w6b, padding=1) * gg.double()).sum() + (F.conv2d(U, w5b, padding=1) * gb.double()).sum()).backward()
+    for a, r in ((xa.grad, xb.grad), (w6a.grad, w6b.grad), (w5a.grad, w5b.grad)):
+        assert float((a.double() - r).abs().max() / r.abs().max()) <= 2e-5
+    # frozen weights: only dL/dx is computed
+    xc = x.clone().requires_grad_(True)
+    g, b = guidance_heads(xc, w6, w5, oh, ow)
+    ((g * gg).sum() + (b * gb).sum()).backward()
+    assert torch.equal(xc.grad, xa.grad)
