@@ -96,64 +96,82 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
 // D[tap][channel] += sum over pixels A[tap][pixel] B[pixel][channel], A = the window value g[o][2i - 1 + r][2j - 1 + k] (tap t = o * 9 + r * 3 + k, padded to 96),
 // B = x[channel][i][j].  v_mfma_f32_32x32x2_f32: A 32 x 2 (lane l: row l % 32, k = l / 32), B 2 x 32 (lane l: k = l / 32, column l % 32), D 32 x 32 in 16
 // registers (lane l: column l % 32; register q: row (q / 4) * 8 + (l / 32) * 4 + q % 4).  A tile = 8 consecutive pixels of an input row: lanes 0-31 take
-// pixels j0 .. j0 + 3, lanes 32-63 pixels j0 + 4 .. j0 + 7, four MFMA steps per (tap block, channel block) -- a lane reads its tap's four window values as 8
-// consecutive floats (stride 2 between pixels) and its channel's four pixels as 16 bytes; the next tile's reads are issued before the current tile's MFMAs.
-constexpr int DW_TILE = 8;
-struct DwTile { float a[3][4]; float bq[2][4]; };
-
-template <int NB>
-__device__ __forceinline__ void dw_load(DwTile& T, const float* __restrict__ x, const float* __restrict__ gg, const float* __restrict__ gb, long long tile, int tiles_w,
-                                        int hfed, int C, int c0, int h, int w, int H, int W, int lane) {
-    const int tw = (int)(tile % tiles_w);
-    const int i = (int)((tile / tiles_w) % hfed), b = (int)(tile / ((long long)tiles_w * hfed));
-    const int half = lane >> 5, id = lane & 31;
-    const int jb = tw * DW_TILE + 4 * half;                     // this lane's first pixel
-    const size_t HWo = (size_t)H * W, hw = (size_t)h * w;
-#pragma unroll
-    for (int tb = 0; tb < 3; ++tb) {
-        const int t = tb * 32 + id;
-        const int o = t / 9, r = (t - o * 9) / 3, k = t - o * 9 - r * 3;
-        const float* src = t >= 81 ? nullptr : (o < 8 ? gg + ((size_t)b * 8 + o) * HWo : (gb ? gb + (size_t)b * HWo : nullptr));
-        const int Y = 2 * i - 1 + r, Xb = 2 * jb - 1 + k;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (src && Y >= 0 && Y < H) {
-            const float* p = src + (size_t)Y * W;
-            if (Xb >= 0 && Xb + 7 < W) {                         // 8 consecutive floats, every other one is a pixel's
-                float q[8];
-                __builtin_memcpy(q, p + Xb, 32);
-                v[0] = q[0]; v[1] = q[2]; v[2] = q[4]; v[3] = q[6];
-            } else {
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) { const int X = Xb + 2 * s_; if (X >= 0 && X < W) v[s_] = p[X]; }
-            }
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) T.a[tb][s_] = v[s_];
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int ch = c0 + nb * 32 + id;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ch < C) {
-            const float* p = x + ((size_t)b * C + ch) * hw + (size_t)i * w;
-            if (jb + 3 < w && 2 * (jb + 3) < W) __builtin_memcpy(v, p + jb, 16);
-            else {
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) { const int j = jb + s_; if (j < w && 2 * j < W) v[s_] = p[j]; }   // (beyond the narrowed output: fed nothing)
-            }
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) T.bq[nb][s_] = v[s_];
-    }
-}
+// pixels j0 .. j0 + 3, lanes 32-63 pixels j0 + 4 .. j0 + 7, four MFMA steps per (tap block, channel block) -- a lane reads its tap's four window values (stride 2
+// between pixels) and its channel's four pixels; the next tile's reads are issued before the current tile's MFMAs.  Timing builds (-DDW_ABL, KITTI x 64): matrix
+// instructions alone 0.73-0.90 ms, the reads alone 1.23 ms, together 1.24: the kernel is bound by its gathers -- a lane reads 16-32 bytes of a line of ITS tap / channel
+// plane, 2.4 GB arrive at 1.9 TB/s.  Staging coalesced rows through LDS would leave the matrix cores as the limit (~0.75 ms); not built.
+#ifndef DW_ABL
+#define DW_ABL 0        // timing builds only: 1 = one tile's values for all tiles (no loads in the loop), 2 = no matrix instructions
+#endif
+#ifndef DW_PX
+#define DW_PX 4          // pixels per lane and tile (8: the same load time, two waves per SIMD instead of three, worse overlap: 1.58 vs 1.24 ms)
+#endif
+constexpr int DW_TILE = 2 * DW_PX;
+struct DwTile { float a[3][DW_PX]; float bq[2][DW_PX]; };
 
 template <int NB>
 __global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ gg, const float* __restrict__ gb,
-                                                             float* __restrict__ part, int C, int c0, int h, int w, int H, int W, long long tiles, int tiles_w,
-                                                             int hfed, int nwave) {
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                             float* __restrict__ part, const float* __restrict__ part_zero, int C, int c0, int h, int w, int H, int W,
+                                                             int tiles, int tiles_w, int hfed, int nwave) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (wave >= nwave) return;
-    const long long t0 = tiles * wave / nwave, t1 = tiles * (wave + 1) / nwave;   // this wave's share of the tiles
+    const int t0 = (int)((long long)tiles * wave / nwave), t1 = (int)((long long)tiles * (wave + 1) / nwave);   // this wave's share of the tiles
+    const int half = lane >> 5, id = lane & 31;
+    const size_t HWo = (size_t)H * W, hw = (size_t)h * w;
+    // what does not change from tile to tile: the lane's taps (one per row block) and channels (one per column block)
+    int tr[3], tk[3];
+    const float* tsrc[3];          // plane of image 0 (a padding row of the block / no blur head: some valid plane, never used)
+    bool tvalid[3];
+    size_t tstep[3];               // from one image to the next
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int t = tb * 32 + id;
+        const int o = t / 9;
+        tr[tb] = (t - o * 9) / 3;
+        tk[tb] = t - o * 9 - tr[tb] * 3;
+        tvalid[tb] = t < 81 && (o < 8 || gb != nullptr);
+        tsrc[tb] = (tvalid[tb] && o == 8) ? gb : gg + (size_t)(o < 8 ? o : 0) * HWo;
+        tstep[tb] = (tvalid[tb] && o == 8) ? HWo : 8 * HWo;
+    }
+    const float* xsrc[NB];
+    bool xvalid[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { const int ch = c0 + nb * 32 + id; xvalid[nb] = ch < C; xsrc[nb] = x + (size_t)(ch < C ? ch : 0) * hw; }
+    const float* zero = part_zero;
+    auto load = [&](DwTile& T, int tw, int i, int b) {       // tile tw of input row i of image b
+        const int jb = tw * DW_TILE + DW_PX * half;             // this lane's first pixel
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+            const int Y = 2 * i - 1 + tr[tb], Xb = 2 * jb - 1 + tk[tb];
+            const bool rowok = tvalid[tb] && Y >= 0 && Y < H;
+            const float* p = tsrc[tb] + (size_t)b * tstep[tb] + (size_t)Y * W;
+            if (!rowok || (Xb >= 0 && Xb + 2 * DW_PX - 1 < W)) {   // the common case: 2 DW_PX consecutive floats, every other one is a pixel's (a row outside: zeros)
+                float q[2 * DW_PX];
+                __builtin_memcpy(q, rowok ? p + Xb : zero, 8 * DW_PX);
+#pragma unroll
+                for (int s_ = 0; s_ < DW_PX; ++s_) T.a[tb][s_] = q[2 * s_];
+            } else {                                             // the first / last tiles of a row: what lies outside reads a zero word
+#pragma unroll
+                for (int s_ = 0; s_ < DW_PX; ++s_) {
+                    const int X = Xb + 2 * s_;
+                    T.a[tb][s_] = *((X >= 0 && X < W) ? p + X : zero);
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float* p = xsrc[nb] + (size_t)b * C * hw + (size_t)i * w;
+            if (!xvalid[nb] || (jb + DW_PX - 1 < w && 2 * (jb + DW_PX - 1) < W)) {
+                __builtin_memcpy(T.bq[nb], xvalid[nb] ? p + jb : zero, 4 * DW_PX);
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < DW_PX; ++s_) {
+                    const int j = jb + s_;
+                    T.bq[nb][s_] = *((j < w && 2 * j < W) ? p + j : zero);      // (beyond the narrowed output: fed nothing)
+                }
+            }
+        }
+    };
     f16v acc[3][NB];
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb)
@@ -162,16 +180,21 @@ __global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[tb][nb][q] = 0.f;
     DwTile nxt;
-    if (t0 < t1) dw_load<NB>(nxt, x, gg, gb, t0, tiles_w, hfed, C, c0, h, w, H, W, lane);
-    for (long long t = t0; t < t1; ++t) {
+    int tw = (int)((unsigned)t0 % (unsigned)tiles_w), ti = (int)(((unsigned)t0 / (unsigned)tiles_w) % (unsigned)hfed), tb_ = (int)((unsigned)t0 / ((unsigned)tiles_w * (unsigned)hfed));
+    if (t0 < t1) load(nxt, tw, ti, tb_);
+    for (int t = t0; t < t1; ++t) {
         const DwTile cur = nxt;
-        if (t + 1 < t1) dw_load<NB>(nxt, x, gg, gb, t + 1, tiles_w, hfed, C, c0, h, w, H, W, lane);
+        if (++tw == tiles_w) { tw = 0; if (++ti == hfed) { ti = 0; ++tb_; } }      // the next tile (scalar)
+        if (!(DW_ABL & 1) && t + 1 < t1) load(nxt, tw, ti, tb_);
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
+        for (int s_ = 0; s_ < DW_PX; ++s_)
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[tb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tb][s_], cur.bq[nb][s_], acc[tb][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (DW_ABL & 2) acc[tb][nb][0] += cur.a[tb][s_] * cur.bq[nb][s_];
+                    else acc[tb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tb][s_], cur.bq[nb][s_], acc[tb][nb], 0, 0, 0);
+                }
     }
     float* dst = part + (size_t)wave * 3 * NB * 16 * 64 + lane;
 #pragma unroll
@@ -181,6 +204,8 @@ __global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 16; ++q) dst[((tb * NB + nb) * 16 + q) * 64] = acc[tb][nb][q];
 }
+
+__global__ void head_zero_line_kernel(float* __restrict__ z) { z[threadIdx.x] = 0.f; }
 
 // dW[o][c][ky][kx] = sum over the waves' partial blocks, in wave order (deterministic)
 __global__ __launch_bounds__(256) void head_bwd_w_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw6, float* __restrict__ dw5, int C, int c0,
@@ -211,7 +236,7 @@ constexpr int DW_MAX_WAVES = 2048;
 static size_t bwdx_bytes(int C) { return (((size_t)C * XREC * sizeof(float)) + 255) & ~(size_t)255; }
 size_t head_backward_workspace(int B, int C, int h, int w) {
     (void)B; (void)C; (void)h; (void)w;
-    return bwdx_bytes(C) + (size_t)DW_MAX_WAVES * 3 * 2 * 16 * 64 * sizeof(float);   // + the waves' partial blocks of dL/dW (64 channels at a time)
+    return bwdx_bytes(C) + 256 + (size_t)DW_MAX_WAVES * 3 * 2 * 16 * 64 * sizeof(float);   // + a line of zeros + the waves' partial blocks of dL/dW (64 channels at a time)
 }
 
 int head_backward(const float* x, const float* w6, const float* w5, const float* gg, const float* gb, float* dx, float* dw6, float* dw5, int B, int C, int h,
@@ -225,16 +250,20 @@ int head_backward(const float* x, const float* w6, const float* w5, const float*
         if (int e = check_launch("head_bwd_x_kernel")) return e;
     }
     if (dw6 || dw5) {
-        float* part = (float*)((char*)ws + bwdx_bytes(C));
+        float* zero = (float*)((char*)ws + bwdx_bytes(C));        // what a tile reads for positions outside the tensors
+        float* part = zero + 64;
+        hipLaunchKernelGGL(head_zero_line_kernel, dim3(1), dim3(64), 0, st, zero);
         const int hfed = (H + 1) / 2 < h ? (H + 1) / 2 : h;     // input rows whose unpooled row lies inside the (narrowed) output
         const int wfed = (W + 1) / 2 < w ? (W + 1) / 2 : w;
         const int tiles_w = (wfed + DW_TILE - 1) / DW_TILE;
-        const long long tiles = (long long)B * hfed * tiles_w;
-        const int nwave = (int)(tiles < DW_MAX_WAVES ? tiles : DW_MAX_WAVES);
+        const long long tiles_ll = (long long)B * hfed * tiles_w;
+        if (tiles_ll >= (1ll << 31)) { set_error("cspn_guidance_head_backward_f32: too many pixels"); return CSPN_E_UNSUPPORTED; }
+        const int tiles = (int)tiles_ll;
+        const int nwave = tiles < DW_MAX_WAVES ? tiles : DW_MAX_WAVES;
         for (int c0 = 0; c0 < C; c0 += 64) {                     // 64 channels at a time (two column blocks of the matrix core)
             const int NB = C - c0 > 32 ? 2 : 1;
-            if (NB == 2) hipLaunchKernelGGL(head_bwd_w_kernel<2>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
-            else hipLaunchKernelGGL(head_bwd_w_kernel<1>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+            if (NB == 2) hipLaunchKernelGGL(head_bwd_w_kernel<2>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+            else hipLaunchKernelGGL(head_bwd_w_kernel<1>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
             hipLaunchKernelGGL(head_bwd_w_reduce_kernel, dim3((81 * NB * 32 + 255) / 256), dim3(256), 0, st, part, dw6, dw5, C, c0, NB, nwave);
         }
         if (int e = check_launch("head_bwd_w_kernel")) return e;
