@@ -75,7 +75,8 @@ LEGEND = {
     "head": "the producer of BASELINE config 3's inputs (SURVEY 8f-2): both guidance heads of the reference backbone (torch_resnet_cspn_nyu.py:187-206, 372-373: Unpool + "
             "3x3 conv 64 -> 8 and 64 -> 1) on a [64,64,152,608] feature map; algorithmic work = the 9 non-zero products per input pixel, input channel and output "
             "plane (2 x 81 x C FLOP per input pixel); head_plus_forward_ms = this head + the headline forward on its outputs, one stream, one event pair; "
-            "torch_heads_ms = the reference's op sequence for the heads (conv_transpose2d + two conv2d, MIOpen) on the same GPU",
+            "torch_heads_ms = the reference's op sequence for the heads (conv_transpose2d + two conv2d, MIOpen) on the same GPU; gradient_ms = "
+            "cspn_guidance_head_backward_f32 on the same shape (dL/dx alone, dL/dW alone; parity: tests/test_head.py)",
     "k_head": "head_raw_kernel (cspn_head.hip): packed fp32 FMAs (no fp32 MFMA gain on gfx950: v_mfma_f32 and v_pk_fma_f32 share the 157.3 TFLOP/s peak), feature "
               "rows by LDS-DMA 8 channels ahead, weights as scalar operands",
     "oracle_head": "oracle/oracle.py guidance_head_oracle (numpy, fp64 accumulation), pinned to the unmodified reference's modules (tests/golden/head_golden.npz)",
@@ -662,6 +663,15 @@ def leg_head(lib, _lib, dev, B, n_iter, norm_name, steps, warmup, prewarm_s):
                      "device_ms_per_launch": round(ms, 4), "device_ms_min": round(dev_ms[0], 4)},
         "head_plus_forward_ms": round(sum(e2e_ms) / len(e2e_ms), 4),
     }
+    try:   # the heads' gradient (cspn_guidance_head_backward_f32): dL/dx by packed FMAs, dL/dW on the fp32 matrix cores; 61.3 GFLOP each
+        from cspn_amd.train_utils import guidance_heads_backward
+        gg_, gb_ = keep["g"].clone(), keep["b"].clone()          # (any dL/dout serves the timing: the heads' own outputs)
+        _, gx_ms = timed_leg(lambda: guidance_heads_backward(x, w6, w5, gg_, gb_, need_w=False), stream, min(steps, 10), 2, 0.0)
+        _, gw_ms = timed_leg(lambda: guidance_heads_backward(x, w6, w5, gg_, gb_, need_x=False), stream, min(steps, 10), 2, 0.0)
+        res["gradient_ms"] = {"grad_x": round(sum(gx_ms) / len(gx_ms), 4), "grad_w": round(sum(gw_ms) / len(gw_ms), 4)}
+        del gg_, gb_
+    except Exception as ex:   # noqa: BLE001
+        res["gradient_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:120])
     try:
         _, t_ms = timed_leg(torch_heads, stream, min(steps, 5), 2, 0.0)
         res["torch_heads_ms"] = round(sum(t_ms) / len(t_ms), 3)
