@@ -265,3 +265,35 @@ def test_head_backward_fuzzed_shapes_and_autograd():
     g, b = guidance_heads(xc, w6, w5, oh, ow)
     ((g * gg).sum() + (b * gb).sum()).backward()
     assert torch.equal(xc.grad, xa.grad)
+
+
+@pytest.mark.gpu
+def test_heads_plus_propagation_train_step_vs_torch_fp64():
+    """the producer and the path as one differentiable pipeline: guidance_heads (raw) -> Affinity_Propagate (training mode: kept checkpoints) -> loss.backward();
+    dL/dx, dL/dweight_guidance, dL/dweight_blur against torch autograd in float64 through the reference's op sequence (conv on the unpooled map + the plain-torch
+    restatement of cspn.py:42-83)"""
+    import torch.nn.functional as F
+    import cspn_amd
+    from cspn_amd.train_utils import guidance_heads
+    sys.path.insert(0, ROOT)
+    from tools.torch_path import cspn2d_torch
+    B, C, h, w, N = 2, 16, 20, 140, 24
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    x = torch.randn(B, C, h, w, generator=gen, device="cuda")
+    w6 = torch.randn(8, C, 3, 3, generator=gen, device="cuda") / 12
+    w5 = torch.randn(1, C, 3, 3, generator=gen, device="cuda") / 12 + 0.05
+    sp = (torch.rand(B, 1, 2 * h, 2 * w, generator=gen, device="cuda") < 0.03).float() * 2.0
+    go = torch.randn(B, 1, 2 * h, 2 * w, generator=gen, device="cuda")
+    xa, w6a, w5a = (t.clone().requires_grad_(True) for t in (x, w6, w5))
+    g, b = guidance_heads(xa, w6a, w5a)
+    out = cspn_amd.Affinity_Propagate(N, 3, "8sum")(g, b, sp)
+    (out * go).sum().backward()
+    xb, w6b, w5b = (t.double().clone().requires_grad_(True) for t in (x, w6, w5))
+    up = torch.zeros(C, 1, 2, 2, device="cuda", dtype=torch.float64)
+    up[:, :, 0, 0] = 1
+    U = F.conv_transpose2d(xb, up, stride=2, groups=C)
+    ref = cspn2d_torch(F.conv2d(U, w6b, padding=1), F.conv2d(U, w5b, padding=1), sp.double(), N, "8sum")
+    (ref * go.double()).sum().backward()
+    assert float((out.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max()) <= 1e-5
+    for a, r, what in ((xa.grad, xb.grad, "x"), (w6a.grad, w6b.grad, "w6"), (w5a.grad, w5b.grad, "w5")):
+        assert float((a.double() - r).abs().max() / r.abs().max()) <= 2e-4, what
