@@ -297,3 +297,27 @@ def test_heads_plus_propagation_train_step_vs_torch_fp64():
     assert float((out.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max()) <= 1e-5
     for a, r, what in ((xa.grad, xb.grad, "x"), (w6a.grad, w6b.grad, "w6"), (w5a.grad, w5b.grad, "w5")):
         assert float((a.double() - r).abs().max() / r.abs().max()) <= 2e-4, what
+
+
+@pytest.mark.gpu
+def test_head_backward_argument_checks():
+    import cspn_amd
+    lib = cspn_amd.load()
+    x = torch.zeros(1, 4, 3, 3, device="cuda")
+    w6, w5 = torch.zeros(8, 4, 3, 3, device="cuda"), torch.zeros(1, 4, 3, 3, device="cuda")
+    gg, gb = torch.zeros(1, 8, 6, 6, device="cuda"), torch.zeros(1, 1, 6, 6, device="cuda")
+    dx, d6, d5 = torch.empty_like(x), torch.empty_like(w6), torch.empty_like(w5)
+    n = lib.cspn_guidance_head_backward_workspace_bytes(1, 4, 3, 3)
+    assert n > 0 and lib.cspn_guidance_head_backward_workspace_bytes(0, 4, 3, 3) == 0
+    ws = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda *a: lib.cspn_guidance_head_backward_f32(*a)   # noqa: E731
+    P = lambda t: t.data_ptr()   # noqa: E731
+    assert call(P(x), P(w6), P(w5), P(gg), P(gb), P(dx), P(d6), P(d5), 1, 4, 3, 3, 6, 6, P(ws), n, st) == 0
+    assert call(P(x), P(w6), P(w5), P(gg), None, P(dx), P(d6), P(d5), 1, 4, 3, 3, 6, 6, P(ws), n, st) == -1        # a blur head without its gradient
+    assert call(P(x), P(w6), None, P(gg), None, P(dx), P(d6), P(d5), 1, 4, 3, 3, 6, 6, P(ws), n, st) == -1         # grad_w_blur without a blur head
+    assert call(P(x), P(w6), P(w5), P(gg), P(gb), P(dx), P(d6), P(d5), 1, 4, 3, 3, 7, 6, P(ws), n, st) == -1       # H > 2 h
+    assert call(P(x), P(w6), P(w5), P(gg), P(gb), P(dx), P(d6), P(d5), 1, 4, 3, 3, 6, 6, P(ws), 64, st) == -2      # workspace too small
+    assert call(None, P(w6), P(w5), P(gg), P(gb), P(dx), P(d6), P(d5), 1, 4, 3, 3, 6, 6, P(ws), n, st) == -1
+    assert call(P(x), P(w6), P(w5), P(gg), P(gb), None, None, None, 1, 4, 3, 3, 6, 6, None, 0, st) == 0            # nothing asked for: nothing needed
+    assert call(P(x), P(w6), P(w5), P(gg), P(gb), P(dx), P(d6), P(d5), 0, 4, 3, 3, 6, 6, None, 0, st) == 0         # empty batch
