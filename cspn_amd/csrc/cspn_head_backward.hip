@@ -8,9 +8,10 @@
 //   * head_bwd_x_kernel: one lane = one input pixel; its 9 x 3 x 3 window of g (81 values) is loaded ONCE into registers (27 8-byte loads + the left column from the
 //     neighbouring lane by DPP), then every channel takes 41 packed FMAs over PAIRS of taps with the weights as scalar operands (the pair-of-channels form
 //     broadcasts g, and the compiler hoists the 81 broadcast pairs out of the channel loop: 168 registers).
-//   * head_bwd_w_kernel: a GEMM -- [81 taps] x [pixels] x [C channels], K = every input pixel of the batch -- on the matrix cores: v_mfma_f32_32x32x2_f32, taps
+//   * head_bwd_w2_kernel: a GEMM -- [81 taps] x [pixels] x [C channels], K = every input pixel of the batch -- on the matrix cores: v_mfma_f32_32x32x2_f32, taps
 //     padded to 96 (3 row blocks), channels in blocks of 32; a wave keeps all 3 x 2 accumulator blocks (96 registers) over its share of the pixels and writes them
-//     once; head_bwd_w_reduce_kernel sums the waves' partial sums in a fixed order (deterministic: no atomics).
+//     once; head_bwd_w_reduce_kernel sums the waves' partial sums in a fixed order (deterministic: no atomics).  Tiles of 32 pixels are read coalesced and go
+//     through the wave's own LDS region into the matrix layout (the first version, head_bwd_w_kernel, gathers them: -DDW_V1).
 #include <cstdint>
 
 #include "cspn_common.h"
@@ -205,6 +206,119 @@ __global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restr
             for (int q = 0; q < 16; ++q) dst[((tb * NB + nb) * 16 + q) * 64] = acc[tb][nb][q];
 }
 
+// ---- dL/dW, second version: the same GEMM fed through LDS.  A wave reads a tile of 32 pixels COALESCED -- lane = pixel: per channel pair one 256-byte load of x,
+// per (plane, window row) one 256-byte load of g (66 columns: + one load for the two left over of all 27 rows) --, drops the values into its OWN LDS region (no
+// barrier: nobody else touches it) and reads them back in the matrix cores' layout (lane = tap / channel; odd pitches: conflict-free).  60 loads, 60 LDS writes,
+// 80 LDS reads and 96 MFMAs per tile against 8 gathers per 24 MFMAs above (kept behind -DDW_V1): 0.98 ms against 1.24 at KITTI x 64.  Timing builds: the matrix
+// instructions with their LDS reads alone 0.66 ms, the loads + LDS writes alone 0.65, together 0.98 with or without the next tile's loads in flight during the MFMAs
+// (two waves per SIMD at 254 registers).
+constexpr int W2_TP = 32, W2_XP = 33, W2_GP = 67;
+template <int NB>
+__global__ __launch_bounds__(256, 2) void head_bwd_w2_kernel(const float* __restrict__ x, const float* __restrict__ gg, const float* __restrict__ gb,
+                                                              float* __restrict__ part, const float* __restrict__ zero, int C, int c0, int h, int w, int H, int W,
+                                                              int tiles, int tiles_w, int hfed, int nwave) {
+    constexpr int XT = NB * 32 * W2_XP, GT = 28 * W2_GP;      // x tile [channel][33]; g tile [27 window rows + a row of zeros][67]
+    __shared__ float lds[4][XT + GT];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (wave >= nwave) return;
+    float* xs = &lds[wv][0];
+    float* gs = &lds[wv][XT];
+    const int t0 = (int)((long long)tiles * wave / nwave), t1 = (int)((long long)tiles * (wave + 1) / nwave);
+    const int half = lane >> 5, id = lane & 31;
+    const size_t HWo = (size_t)H * W, hw = (size_t)h * w;
+    for (int q = lane; q < W2_GP; q += 64) gs[27 * W2_GP + q] = 0.f;          // the row the padding taps read
+    // where this lane's taps / channels sit in the tile (MFMA layout)
+    int aoff[3], boff[NB];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int t = tb * 32 + id;
+        const int o = t / 9, r = (t - o * 9) / 3, k = t - o * 9 - r * 3;
+        aoff[tb] = (t < 81 ? (o * 3 + r) * W2_GP + k : 27 * W2_GP) + 2 * 16 * half;     // + 2 px per step
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) boff[nb] = (nb * 32 + id) * W2_XP + 16 * half;
+    f16v acc[3][NB];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[tb][nb][q] = 0.f;
+    int tw = (int)((unsigned)t0 % (unsigned)tiles_w), ti = (int)(((unsigned)t0 / (unsigned)tiles_w) % (unsigned)hfed), tb_ = (int)((unsigned)t0 / ((unsigned)tiles_w * (unsigned)hfed));
+    // x: a channel pair per load (lanes 0-31: channel 2p, lanes 32-63: channel 2p + 1; lane & 31 = pixel).  The NEXT tile's x is requested before this tile's matrix
+    // instructions and waits in registers
+    float xv[NB * 16];
+    auto load_x = [&](int tw_, int i_, int b_) {
+        const int j = tw_ * W2_TP + id;
+        const bool pok = j < w && 2 * j < W;
+        const float* px = x + (size_t)b_ * C * hw + (size_t)i_ * w + j;
+#pragma unroll
+        for (int p = 0; p < NB * 16; ++p) {
+            const int ch = c0 + 2 * p + half;
+            xv[p] = *((pok && ch < C) ? px + (size_t)ch * hw : zero);
+        }
+    };
+    // g: window row rr = o * 3 + r of the tile: columns 2 j0 - 1 .. 2 j0 + 64 (lane = column), then the two columns left over of all 27 rows at once; also requested
+    // a tile ahead (every load first, the LDS writes a tile later: a write next to its load makes each load wait on its own)
+    float gv[28];
+    auto load_g = [&](int tw_, int i_, int b_) {
+        const int j0_ = tw_ * W2_TP;
+        const int X = 2 * j0_ - 1 + lane;
+        const bool cok = X >= 0 && X < W;
+        const int rl = lane >> 1, X2 = 2 * j0_ + 63 + (lane & 1);
+        const int ol = rl / 3, Yl = 2 * i_ - 1 + (rl - ol * 3);
+        const bool hasb = gb != nullptr;
+        const float* gimg = gg + (size_t)b_ * 8 * HWo;
+        const float* bimg = hasb ? gb + (size_t)b_ * HWo : zero;
+#pragma unroll
+        for (int rr = 0; rr < 27; ++rr) {
+            const int o = rr / 3, r = rr - o * 3, Y = 2 * i_ - 1 + r;
+            const float* src = o < 8 ? gimg + (size_t)o * HWo : bimg;
+            const bool ok = cok && Y >= 0 && Y < H && (o < 8 || hasb);
+            gv[rr] = *(ok ? src + (size_t)Y * W + X : zero);
+        }
+        const float* src = ol < 8 ? gimg + (size_t)ol * HWo : bimg;
+        const bool ok = lane < 54 && X2 < W && Yl >= 0 && Yl < H && (ol < 8 || hasb);
+        gv[27] = *(ok ? src + (size_t)Yl * W + X2 : zero);
+    };
+    if (t0 < t1) { load_x(tw, ti, tb_); load_g(tw, ti, tb_); }
+    for (int t = t0; t < t1; ++t) {
+        if (!(DW_ABL & 1) || t == t0) {
+#pragma unroll
+        for (int p = 0; p < NB * 16; ++p) xs[(2 * p + half) * W2_XP + id] = xv[p];
+#pragma unroll
+        for (int rr = 0; rr < 27; ++rr) gs[rr * W2_GP + lane] = gv[rr];
+        if (lane < 54) gs[(lane >> 1) * W2_GP + 64 + (lane & 1)] = gv[27];
+        }   // (DW_ABL & 1: the first tile's values for every tile)
+        if (++tw == tiles_w) { tw = 0; if (++ti == hfed) { ti = 0; ++tb_; } }
+        if (!(DW_ABL & 1) && t + 1 < t1) { load_x(tw, ti, tb_); load_g(tw, ti, tb_); }
+        // ---- 16 steps of two pixels (s, s + 16)
+#pragma unroll 4
+        for (int s_ = 0; s_ < 16; ++s_) {
+            float av[3], bv[NB];
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) av[tb] = gs[aoff[tb] + 2 * s_];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = xs[boff[nb] + s_];
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (DW_ABL & 2) acc[tb][nb][0] += av[tb] * bv[nb];
+                    else acc[tb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tb], bv[nb], acc[tb][nb], 0, 0, 0);
+                }
+        }
+    }
+    float* dst = part + (size_t)wave * 3 * NB * 16 * 64 + lane;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dst[((tb * NB + nb) * 16 + q) * 64] = acc[tb][nb][q];
+}
+
 __global__ void head_zero_line_kernel(float* __restrict__ z) { z[threadIdx.x] = 0.f; }
 
 // dW[o][c][ky][kx] = sum over the waves' partial blocks, in wave order (deterministic)
@@ -255,15 +369,24 @@ int head_backward(const float* x, const float* w6, const float* w5, const float*
         hipLaunchKernelGGL(head_zero_line_kernel, dim3(1), dim3(64), 0, st, zero);
         const int hfed = (H + 1) / 2 < h ? (H + 1) / 2 : h;     // input rows whose unpooled row lies inside the (narrowed) output
         const int wfed = (W + 1) / 2 < w ? (W + 1) / 2 : w;
+#ifdef DW_V1
         const int tiles_w = (wfed + DW_TILE - 1) / DW_TILE;
+#else
+        const int tiles_w = (wfed + W2_TP - 1) / W2_TP;
+#endif
         const long long tiles_ll = (long long)B * hfed * tiles_w;
         if (tiles_ll >= (1ll << 31)) { set_error("cspn_guidance_head_backward_f32: too many pixels"); return CSPN_E_UNSUPPORTED; }
         const int tiles = (int)tiles_ll;
         const int nwave = tiles < DW_MAX_WAVES ? tiles : DW_MAX_WAVES;
         for (int c0 = 0; c0 < C; c0 += 64) {                     // 64 channels at a time (two column blocks of the matrix core)
             const int NB = C - c0 > 32 ? 2 : 1;
+#ifndef DW_V1
+            if (NB == 2) hipLaunchKernelGGL(head_bwd_w2_kernel<2>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+            else hipLaunchKernelGGL(head_bwd_w2_kernel<1>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+#else
             if (NB == 2) hipLaunchKernelGGL(head_bwd_w_kernel<2>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
             else hipLaunchKernelGGL(head_bwd_w_kernel<1>, dim3((nwave + 3) / 4), dim3(256), 0, st, x, gg, gb, part, zero, C, c0, h, w, H, W, tiles, tiles_w, hfed, nwave);
+#endif
             hipLaunchKernelGGL(head_bwd_w_reduce_kernel, dim3((81 * NB * 32 + 255) / 256), dim3(256), 0, st, part, dw6, dw5, C, c0, NB, nwave);
         }
         if (int e = check_launch("head_bwd_w_kernel")) return e;
