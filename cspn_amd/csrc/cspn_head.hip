@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, HEAD_OCC) void head_raw_kernel(const float* __
             const float* q2 = (const float*)((const char*)q1 + d2);
             asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\ts_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
                          "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3"
-                         :: "v"(voff), "s"(q0), "s"(q1), "s"(q2), "s"(dst) : "memory");
+                         :: "v"(voff), "s"(q0), "s"(q1), "s"(q2), "s"(dst) : "memory", "m0", "scc");
         };
         auto lds = [&](unsigned a) { return *(const volatile __attribute__((address_space(3))) float*)a; };
         auto right = [&](float t) {   // the value of the lane to the right (column j + 1); lane 63: 0, it owns no output
