@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_w_kernel(const float* __restr
 // ---- dL/dW, second version: the same GEMM fed through LDS.  A wave reads a tile of 32 pixels COALESCED -- lane = pixel: per channel pair one 256-byte load of x,
 // per (plane, window row) one 256-byte load of g (66 columns: + one load for the two left over of all 27 rows) --, drops the values into its OWN LDS region (no
 // barrier: nobody else touches it) and reads them back in the matrix cores' layout (lane = tap / channel; odd pitches: conflict-free).  60 loads, 60 LDS writes,
-// 80 LDS reads and 96 MFMAs per tile against 8 gathers per 24 MFMAs above (kept behind -DDW_V1): 0.98 ms against 1.24 at KITTI x 64.  Timing builds: the matrix
+// 80 LDS reads and 96 MFMAs per tile against 8 gathers per 24 MFMAs above (kept behind -DDW_V1): 0.94 ms against 1.24 at KITTI x 64.  Timing builds: the matrix
 // instructions with their LDS reads alone 0.66 ms, the loads + LDS writes alone 0.65, together 0.98 with or without the next tile's loads in flight during the MFMAs
 // (two waves per SIMD at 254 registers).
 constexpr int W2_TP = 32, W2_XP = 33, W2_GP = 67;
@@ -248,48 +248,61 @@ __global__ __launch_bounds__(256, 2) void head_bwd_w2_kernel(const float* __rest
     int tw = (int)((unsigned)t0 % (unsigned)tiles_w), ti = (int)(((unsigned)t0 / (unsigned)tiles_w) % (unsigned)hfed), tb_ = (int)((unsigned)t0 / ((unsigned)tiles_w * (unsigned)hfed));
     // x: a channel pair per load (lanes 0-31: channel 2p, lanes 32-63: channel 2p + 1; lane & 31 = pixel).  The NEXT tile's x is requested before this tile's matrix
     // instructions and waits in registers
+    // Every load is (scalar row / plane address) + (one 32-bit lane offset, clamped into the row): no per-load vector address arithmetic; what lies outside is
+    // zeroed when the value goes to LDS a tile later (the masks are recomputed there).
     float xv[NB * 16];
+    auto ld = [&](const float* sbase, unsigned voff) { return *(const float*)((const char*)sbase + voff); };
     auto load_x = [&](int tw_, int i_, int b_) {
         const int j = tw_ * W2_TP + id;
-        const bool pok = j < w && 2 * j < W;
-        const float* px = x + (size_t)b_ * C * hw + (size_t)i_ * w + j;
+        const unsigned voff0 = 4u * (unsigned)(j < w ? j : w - 1);
+        const unsigned voff = voff0 + 4u * (unsigned)half * (unsigned)hw;      // lanes 32-63: the pair's second channel
+        const float* row = x + ((size_t)b_ * C + c0) * hw + (size_t)i_ * w;
+        const int nch = C - c0;                                              // channels left in this column block
 #pragma unroll
         for (int p = 0; p < NB * 16; ++p) {
-            const int ch = c0 + 2 * p + half;
-            xv[p] = *((pok && ch < C) ? px + (size_t)ch * hw : zero);
+            // (uniform: a pair's first channel clamped into the tensor; a pair without its second channel reads the first for both halves: masked later)
+            const int cp = 2 * p < nch ? 2 * p : nch - 1;
+            xv[p] = ld(row + (size_t)cp * hw, 2 * p + 1 < nch ? voff : voff0);
         }
     };
-    // g: window row rr = o * 3 + r of the tile: columns 2 j0 - 1 .. 2 j0 + 64 (lane = column), then the two columns left over of all 27 rows at once; also requested
-    // a tile ahead (every load first, the LDS writes a tile later: a write next to its load makes each load wait on its own)
     float gv[28];
     auto load_g = [&](int tw_, int i_, int b_) {
         const int j0_ = tw_ * W2_TP;
         const int X = 2 * j0_ - 1 + lane;
-        const bool cok = X >= 0 && X < W;
+        const unsigned voff = 4u * (unsigned)(X < 0 ? 0 : (X >= W ? W - 1 : X));
         const int rl = lane >> 1, X2 = 2 * j0_ + 63 + (lane & 1);
-        const int ol = rl / 3, Yl = 2 * i_ - 1 + (rl - ol * 3);
+        const int ol = rl < 27 ? rl / 3 : 0, Yl = 2 * i_ - 1 + (rl < 27 ? rl - ol * 3 : 0);
         const bool hasb = gb != nullptr;
         const float* gimg = gg + (size_t)b_ * 8 * HWo;
-        const float* bimg = hasb ? gb + (size_t)b_ * HWo : zero;
+        const float* bimg = hasb ? gb + (size_t)b_ * HWo : gimg;
 #pragma unroll
         for (int rr = 0; rr < 27; ++rr) {
             const int o = rr / 3, r = rr - o * 3, Y = 2 * i_ - 1 + r;
             const float* src = o < 8 ? gimg + (size_t)o * HWo : bimg;
-            const bool ok = cok && Y >= 0 && Y < H && (o < 8 || hasb);
-            gv[rr] = *(ok ? src + (size_t)Y * W + X : zero);
+            gv[rr] = ld(src + (size_t)(Y < 0 ? 0 : (Y >= H ? H - 1 : Y)) * W, voff);
         }
-        const float* src = ol < 8 ? gimg + (size_t)ol * HWo : bimg;
-        const bool ok = lane < 54 && X2 < W && Yl >= 0 && Yl < H && (ol < 8 || hasb);
-        gv[27] = *(ok ? src + (size_t)Yl * W + X2 : zero);
+        const float* src = (ol < 8 || !hasb) ? gimg + (size_t)(ol < 8 ? ol : 0) * HWo : bimg;                  // (per lane: the one gather of the tile)
+        gv[27] = src[(size_t)(Yl < 0 ? 0 : (Yl >= H ? H - 1 : Yl)) * W + (X2 < W ? X2 : W - 1)];
     };
     if (t0 < t1) { load_x(tw, ti, tb_); load_g(tw, ti, tb_); }
     for (int t = t0; t < t1; ++t) {
         if (!(DW_ABL & 1) || t == t0) {
+        {   // the tile whose values arrived: tw, ti, tb_ still name it
+            const int j = tw * W2_TP + id;
+            const bool pok = j < w && 2 * j < W;                  // (beyond the narrowed output: fed nothing)
 #pragma unroll
-        for (int p = 0; p < NB * 16; ++p) xs[(2 * p + half) * W2_XP + id] = xv[p];
+            for (int p = 0; p < NB * 16; ++p) xs[(2 * p + half) * W2_XP + id] = (pok && c0 + 2 * p + half < C) ? xv[p] : 0.f;
+            const int X = 2 * tw * W2_TP - 1 + lane;
+            const bool cok = X >= 0 && X < W, hasb = gb != nullptr;
 #pragma unroll
-        for (int rr = 0; rr < 27; ++rr) gs[rr * W2_GP + lane] = gv[rr];
-        if (lane < 54) gs[(lane >> 1) * W2_GP + 64 + (lane & 1)] = gv[27];
+            for (int rr = 0; rr < 27; ++rr) {
+                const int o = rr / 3, r = rr - o * 3, Y = 2 * ti - 1 + r;
+                gs[rr * W2_GP + lane] = (cok && Y >= 0 && Y < H && (o < 8 || hasb)) ? gv[rr] : 0.f;
+            }
+            const int rl = lane >> 1, X2 = 2 * tw * W2_TP + 63 + (lane & 1);
+            const int ol = rl / 3, Yl = 2 * ti - 1 + (rl - ol * 3);
+            if (lane < 54) gs[rl * W2_GP + 64 + (lane & 1)] = (X2 < W && Yl >= 0 && Yl < H && (ol < 8 || hasb)) ? gv[27] : 0.f;
+        }
         }   // (DW_ABL & 1: the first tile's values for every tile)
         if (++tw == tiles_w) { tw = 0; if (++ti == hfed) { ti = 0; ++tb_; } }
         if (!(DW_ABL & 1) && t + 1 < t1) { load_x(tw, ti, tb_); load_g(tw, ti, tb_); }
